@@ -1,0 +1,616 @@
+/*
+ * t3_oracle.c -- CPU ORACLE for the T3 speech-token decode path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (chatterbox-vllm2_amd/, include/)
+ * may include, link, import or execute this file.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it, and only as the checker / the timed CPU baseline.
+ *
+ * What it restates (reference = groxaxo/chatterbox-vllm2, paths relative to /root/reference):
+ *   - prompt/embedding layout ............ src/chatterbox_vllm/models/t3/t3.py:189-221, 542-561
+ *   - decode embedding ................... t3.py:440-486 (speech position index: SURVEY.md section 9 Q1)
+ *   - dual-stream CFG forward ............ t3.py:696-713
+ *   - CFG logits ......................... t3.py:650-673 (bf16 tensor arithmetic, t3.py:662)
+ *   - Llama hyper-parameters ............. t3-model/config.json:1-33
+ *   - constants .......................... models/t3/modules/t3_config.py:1-38, t3.py:38-49
+ *   - sampling parameters ................ tts.py:455-464
+ * The Llama block arithmetic, paged attention and the sampler live in vllm==0.10.0
+ * (pyproject.toml:29), which is NOT in /root/reference and not installable here, and the
+ * reference has no tests or golden vectors for this path:  PARITY UNPINNED by the reference
+ * itself.  The oracle is pinned instead against (a) transformers.LlamaModel on the same
+ * weights (tests/test_oracle_vs_hf.py), (b) the reference's importable leaf modules
+ * (tests/golden/make_golden.py), (c) committed golden token streams.
+ *
+ * NUMERICS CONTRACT (DESIGN.md "Numerics contract"): every rounding point and every
+ * floating-point summation ORDER below is part of the specification.  The HIP kernels
+ * implement the same orders, so logits and token ids are bit-identical, not just close.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define T3_D 1024
+#define T3_H 16
+#define T3_HD 64
+#define T3_F 4096
+#define T3_V 8194          /* speech vocab, t3_config.py:10 */
+#define T3_COND 34         /* t3.py:42 */
+#define T3_BOS 6561        /* start_speech_token, t3_config.py:8 */
+#define T3_EOS 6562        /* stop_speech_token,  t3_config.py:9 */
+#define T3_TEXT_POS 2050   /* t3.py:280 */
+#define T3_SPEECH_POS 4100 /* t3.py:283 */
+#define T3_EPS 1e-5f       /* config.json:20 */
+#define T3_CHUNK 64        /* attention chunk == KV block, in tokens */
+
+/* ------------------------------------------------------------------ scalar helpers */
+static inline float bf2f(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f;
+}
+/* fp32 -> bf16, round to nearest even (NaN kept quiet) */
+static inline uint16_t f2bf(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float rbf(float f) { return bf2f(f2bf(f)); }
+
+/* Contract exp: Cody-Waite reduction + degree-6 Horner, only fma/mul/rint, so that the
+ * GPU evaluates the identical sequence.  |rel err| ~ 1e-7.  Domain clamp [-87, 88]. */
+float orc_expf(float x) {
+    if (!(x >= -87.0f)) return 0.0f;      /* also -inf and NaN -> 0 */
+    if (x > 88.0f) x = 88.0f;
+    float n = rintf(x * 1.44269502162933349609375f);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.428606765330187045e-06f, r);
+    float p = 1.388888922519981861e-03f;            /* 1/720 */
+    p = fmaf(p, r, 8.333333767950534821e-03f);      /* 1/120 */
+    p = fmaf(p, r, 4.166666790843009949e-02f);      /* 1/24  */
+    p = fmaf(p, r, 1.666666716337203979e-01f);      /* 1/6   */
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    int32_t ni = (int32_t)n;
+    uint32_t sb = (uint32_t)(ni + 127) << 23; float s; memcpy(&s, &sb, 4);
+    return p * s;
+}
+
+/* ------------------------------------------------------------------ GEMM
+ * y[m][n] = sum_k x[m][k] * W[n][k], x and W bf16 (products are exact in fp32).
+ * Order: K is cut into 4 equal contiguous segments; inside a segment, 32-wide k-blocks
+ * ascending; inside a block k = 8q + j visited j = 0..7 outer, q = 0..3 inner; each step
+ * acc = acc + x*w starting from +0; result = ((p0 + p1) + p2) + p3.
+ * Wt is the weight TRANSPOSED, [K][N] bf16 (oracle-internal storage).                  */
+#define GEMM_NB 256
+#define GEMM_MB 8
+void orc_gemm(const uint16_t* x, const uint16_t* Wt, int M, int K, int N, float* out) {
+    const int seg_len = K / 4;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int nb = 0; nb < N; nb += GEMM_NB) {
+        const int nw = (N - nb < GEMM_NB) ? (N - nb) : GEMM_NB;
+        float acc[GEMM_MB][GEMM_NB], res[GEMM_MB][GEMM_NB], wf[GEMM_NB];
+        for (int m0 = 0; m0 < M; m0 += GEMM_MB) {
+            const int mw = (M - m0 < GEMM_MB) ? (M - m0) : GEMM_MB;
+            for (int seg = 0; seg < 4; ++seg) {
+                for (int r = 0; r < mw; ++r) for (int n = 0; n < nw; ++n) acc[r][n] = 0.0f;
+                for (int kb = seg * seg_len; kb < (seg + 1) * seg_len; kb += 32)
+                    for (int j = 0; j < 8; ++j)
+                        for (int q = 0; q < 4; ++q) {
+                            const int k = kb + 8 * q + j;
+                            const uint16_t* wrow = Wt + (size_t)k * N + nb;
+                            for (int n = 0; n < nw; ++n) wf[n] = bf2f(wrow[n]);
+                            for (int r = 0; r < mw; ++r) {
+                                const float xv = bf2f(x[(size_t)(m0 + r) * K + k]);
+                                float* a = acc[r];
+                                for (int n = 0; n < nw; ++n) a[n] = fmaf(xv, wf[n], a[n]);
+                            }
+                        }
+                for (int r = 0; r < mw; ++r)
+                    for (int n = 0; n < nw; ++n)
+                        res[r][n] = (seg == 0) ? acc[r][n] : (res[r][n] + acc[r][n]);
+            }
+            for (int r = 0; r < mw; ++r)
+                memcpy(out + (size_t)(m0 + r) * N + nb, res[r], sizeof(float) * nw);
+        }
+    }
+}
+
+/* Helper for tests: W given in its natural [N][K] layout. */
+void orc_gemm_nk(const uint16_t* x, const uint16_t* W, int M, int K, int N, float* out) {
+    uint16_t* Wt = (uint16_t*)malloc((size_t)K * N * 2);
+    for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) Wt[(size_t)k * N + n] = W[(size_t)n * K + k];
+    orc_gemm(x, Wt, M, K, N, out);
+    free(Wt);
+}
+
+/* ------------------------------------------------------------------ 64-lane butterfly */
+static void bfly_add(float v[64], const int* offs, int n) {
+    float t[64];
+    for (int s = 0; s < n; ++s) {
+        for (int l = 0; l < 64; ++l) t[l] = v[l] + v[l ^ offs[s]];
+        memcpy(v, t, sizeof(t));
+    }
+}
+
+/* ------------------------------------------------------------------ RMSNorm
+ * One row of 1024 bf16.  Lane l (0..63) owns elements 8l..8l+7 then 512+8l..512+8l+7,
+ * ss_l = sequential x*x adds; butterfly add over xor 32,16,8,4,2,1;
+ * rstd = 1/sqrt(ss/1024 + eps) (IEEE sqrt, IEEE divide);
+ * y = bf16( bf16(x*rstd) * w )          (the double rounding mirrors vLLM / HF Llama).   */
+void orc_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* y, int rows) {
+    static const int offs[6] = {32, 16, 8, 4, 2, 1};
+    for (int r = 0; r < rows; ++r) {
+        const uint16_t* xr = x + (size_t)r * T3_D; uint16_t* yr = y + (size_t)r * T3_D;
+        float ss[64];
+        for (int l = 0; l < 64; ++l) {
+            float a = 0.0f;
+            for (int e = 0; e < 8; ++e) { float v = bf2f(xr[8 * l + e]); a = fmaf(v, v, a); }
+            for (int e = 0; e < 8; ++e) { float v = bf2f(xr[512 + 8 * l + e]); a = fmaf(v, v, a); }
+            ss[l] = a;
+        }
+        bfly_add(ss, offs, 6);
+        const float rstd = 1.0f / sqrtf(ss[0] * (1.0f / 1024.0f) + T3_EPS);
+        for (int i = 0; i < T3_D; ++i) {
+            float n = rbf(bf2f(xr[i]) * rstd);
+            yr[i] = f2bf(n * bf2f(w[i]));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ RoPE table (llama3 scaling)
+ * config.json:21-28.  inv_freq in double, angle = pos * inv_freq in double, cos/sin in
+ * double -> fp32 -> bf16 (the cache is held in the model dtype as vLLM/HF do).
+ * The product's host code computes the same table the same way.                         */
+void orc_rope_table(int max_pos, float* cos_t, float* sin_t /* [max_pos][32] */) {
+    double inv[32];
+    const double theta = 500000.0, factor = 8.0, lo = 1.0, hi = 4.0, old = 8192.0;
+    const double pi = 3.14159265358979323846;
+    for (int i = 0; i < 32; ++i) {
+        double f = pow(theta, -(2.0 * i) / 64.0);
+        double wl = 2.0 * pi / f;
+        if (wl > old / lo) f = f / factor;
+        else if (wl >= old / hi) {
+            double s = (old / wl - lo) / (hi - lo);
+            f = (1.0 - s) * f / factor + s * f;
+        }
+        inv[i] = (double)(float)f;       /* inv_freq is an fp32 buffer in HF */
+    }
+    for (int p = 0; p < max_pos; ++p)
+        for (int i = 0; i < 32; ++i) {
+            double a = (double)p * inv[i];
+            cos_t[p * 32 + i] = rbf((float)cos(a));
+            sin_t[p * 32 + i] = rbf((float)sin(a));
+        }
+}
+
+/* rotate one 64-wide head in place (bf16), rotate-half pairing (i, i+32) */
+static void rope_head(uint16_t* v, const float* c, const float* s) {
+    for (int i = 0; i < 32; ++i) {
+        float x1 = bf2f(v[i]), x2 = bf2f(v[i + 32]);
+        float o1 = x1 * c[i] - x2 * s[i];     /* both products exact (bf16 x bf16) */
+        float o2 = x2 * c[i] + x1 * s[i];
+        v[i] = f2bf(o1); v[i + 32] = f2bf(o2);
+    }
+}
+void orc_rope(uint16_t* qk /* [rows][1024] */, const int* pos, int rows, const float* cos_t, const float* sin_t) {
+    for (int r = 0; r < rows; ++r)
+        for (int h = 0; h < T3_H; ++h)
+            rope_head(qk + (size_t)r * T3_D + h * T3_HD, cos_t + pos[r] * 32, sin_t + pos[r] * 32);
+}
+
+/* ------------------------------------------------------------------ attention (one query row, one head)
+ * K,V: [L][stride] bf16 with this head's 64 values at kv[t*stride .. +64).
+ * Context is cut into position-aligned chunks of 64 tokens.  Inside chunk c, "lane"
+ * l = 8g + e8 handles tokens t = 64c + 8i + g (i = 0..7) and dims 8*e8 .. 8*e8+7:
+ *   score partial = sequential q*k adds over the lane's 8 dims; butterfly add xor 1,2,4;
+ *   s = partial * 0.125; masked (t >= L) -> -inf
+ *   m_c = max over i, then over lanes (exact);  p = exp(s - m_c), masked -> 0
+ *   l_c: per lane sequential add over i, butterfly add xor 8,16,32
+ *   o_c[d]: per lane o = fma(p_i, v, o) over i, butterfly add xor 8,16,32
+ * Across chunks: M = max m_c; ascending c: w = exp(m_c - M); l = fma(w, l_c, l);
+ *   o[d] = fma(w, o_c[d], o[d]);  out[d] = bf16(o[d] / l).                               */
+void orc_attn_row(const uint16_t* q, const uint16_t* K, const uint16_t* Vv, int L, int stride, uint16_t* out) {
+    static const int o124[3] = {1, 2, 4}, o8[3] = {8, 16, 32};
+    const int nc = (L + T3_CHUNK - 1) / T3_CHUNK;
+    float* mc = (float*)malloc(sizeof(float) * nc);
+    float* lc = (float*)malloc(sizeof(float) * nc);
+    float* oc = (float*)malloc(sizeof(float) * nc * 64);
+    float qf[64];
+    for (int d = 0; d < 64; ++d) qf[d] = bf2f(q[d]);
+    for (int c = 0; c < nc; ++c) {
+        float s[8][64], p[8][64];
+        for (int i = 0; i < 8; ++i) {
+            float part[64];
+            for (int l = 0; l < 64; ++l) {
+                const int g = l >> 3, e0 = (l & 7) * 8, t = 64 * c + 8 * i + g;
+                float a = 0.0f;
+                if (t < L) for (int e = 0; e < 8; ++e) a = fmaf(qf[e0 + e], bf2f(K[(size_t)t * stride + e0 + e]), a);
+                part[l] = a;
+            }
+            bfly_add(part, o124, 3);
+            for (int l = 0; l < 64; ++l) {
+                const int t = 64 * c + 8 * i + (l >> 3);
+                s[i][l] = (t < L) ? part[l] * 0.125f : -INFINITY;
+            }
+        }
+        float m = -INFINITY;
+        for (int i = 0; i < 8; ++i) for (int l = 0; l < 64; ++l) m = fmaxf(m, s[i][l]);
+        float ls[64];
+        for (int l = 0; l < 64; ++l) {
+            float a = 0.0f;
+            for (int i = 0; i < 8; ++i) {
+                p[i][l] = (s[i][l] == -INFINITY) ? 0.0f : orc_expf(s[i][l] - m);
+                a = a + p[i][l];
+            }
+            ls[l] = a;
+        }
+        bfly_add(ls, o8, 3);
+        float o[8][64];   /* o[e][lane] */
+        for (int l = 0; l < 64; ++l) {
+            const int g = l >> 3, e0 = (l & 7) * 8;
+            for (int e = 0; e < 8; ++e) {
+                float a = 0.0f;
+                for (int i = 0; i < 8; ++i) {
+                    const int t = 64 * c + 8 * i + g;
+                    const float v = (t < L) ? bf2f(Vv[(size_t)t * stride + e0 + e]) : 0.0f;
+                    a = fmaf(p[i][l], v, a);
+                }
+                o[e][l] = a;
+            }
+        }
+        for (int e = 0; e < 8; ++e) bfly_add(o[e], o8, 3);
+        mc[c] = m; lc[c] = ls[0];
+        for (int e8 = 0; e8 < 8; ++e8) for (int e = 0; e < 8; ++e) oc[c * 64 + e8 * 8 + e] = o[e][e8];
+    }
+    float M = -INFINITY;
+    for (int c = 0; c < nc; ++c) M = fmaxf(M, mc[c]);
+    float l = 0.0f, o[64];
+    for (int d = 0; d < 64; ++d) o[d] = 0.0f;
+    for (int c = 0; c < nc; ++c) {
+        const float w = orc_expf(mc[c] - M);
+        l = fmaf(w, lc[c], l);
+        for (int d = 0; d < 64; ++d) o[d] = fmaf(w, oc[c * 64 + d], o[d]);
+    }
+    for (int d = 0; d < 64; ++d) out[d] = f2bf(o[d] / l);
+    free(mc); free(lc); free(oc);
+}
+
+/* SwiGLU: act = bf16( bf16(silu(g)) * u ),  silu(g) = g / (1 + exp(-g)) */
+static inline uint16_t silu_mul(uint16_t g, uint16_t u) {
+    const float gf = bf2f(g);
+    const float sg = rbf(gf / (1.0f + orc_expf(-gf)));
+    return f2bf(sg * bf2f(u));
+}
+void orc_silu_mul(const uint16_t* g, const uint16_t* u, uint16_t* out, int n) {
+    for (int i = 0; i < n; ++i) out[i] = silu_mul(g[i], u[i]);
+}
+
+/* ------------------------------------------------------------------ model */
+typedef struct {
+    uint16_t *wqkv_t;   /* [1024][3072]  (transposed: [K][N]) rows n: q(0..1023) k v */
+    uint16_t *wo_t;     /* [1024][1024] */
+    uint16_t *wgu_t;    /* [1024][8192]  n: gate(0..4095) up(4096..8191) */
+    uint16_t *wd_t;     /* [4096][1024] */
+    uint16_t *ln1, *ln2;/* [1024] */
+} OrcLayer;
+
+typedef struct {
+    int n_layers, text_vocab, max_pos;
+    OrcLayer* layers;
+    uint16_t *norm, *text_emb, *speech_emb, *text_pos, *speech_pos, *head_t /* [1024][8194] */;
+    float *cos_t, *sin_t;
+    /* KV cache: [stream][layer][pos][2][1024] bf16 */
+    int n_streams; uint16_t* kv;
+} OrcModel;
+
+OrcModel* orc_create(int n_layers, int text_vocab, int max_pos, int n_streams) {
+    OrcModel* m = (OrcModel*)calloc(1, sizeof(OrcModel));
+    m->n_layers = n_layers; m->text_vocab = text_vocab; m->max_pos = max_pos; m->n_streams = n_streams;
+    m->layers = (OrcLayer*)calloc(n_layers, sizeof(OrcLayer));
+    m->cos_t = (float*)malloc(sizeof(float) * max_pos * 32);
+    m->sin_t = (float*)malloc(sizeof(float) * max_pos * 32);
+    orc_rope_table(max_pos, m->cos_t, m->sin_t);
+    m->kv = (uint16_t*)calloc((size_t)n_streams * n_layers * max_pos * 2 * T3_D, 2);
+    return m;
+}
+
+static uint16_t* dup_t(const uint16_t* W, int N, int K) {  /* [N][K] -> [K][N] */
+    uint16_t* t = (uint16_t*)malloc((size_t)N * K * 2);
+    for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) t[(size_t)k * N + n] = W[(size_t)n * K + k];
+    return t;
+}
+static uint16_t* dup(const uint16_t* W, size_t n) { uint16_t* t = (uint16_t*)malloc(n * 2); memcpy(t, W, n * 2); return t; }
+
+/* Tensor names follow the checkpoint (t3.py:300-332, tts.py:112-137): "tfmr.layers.N.self_attn.q_proj.weight" ...
+ * All tensors bf16, natural [out][in] layout.  Returns 0 ok, -1 unknown name (ignored, as t3.py:316-319). */
+int orc_set_tensor(OrcModel* m, const char* name, const uint16_t* data, int rows, int cols) {
+    int L; char rest[128];
+    if (sscanf(name, "tfmr.layers.%d.%127s", &L, rest) == 2) {
+        if (L < 0 || L >= m->n_layers) return -1;
+        OrcLayer* y = &m->layers[L];
+        if (!y->wqkv_t) { y->wqkv_t = (uint16_t*)calloc((size_t)T3_D * 3072, 2); y->wgu_t = (uint16_t*)calloc((size_t)T3_D * 8192, 2); }
+        int off = -1, isgu = 0;
+        if (!strcmp(rest, "self_attn.q_proj.weight")) off = 0;
+        else if (!strcmp(rest, "self_attn.k_proj.weight")) off = 1024;
+        else if (!strcmp(rest, "self_attn.v_proj.weight")) off = 2048;
+        else if (!strcmp(rest, "mlp.gate_proj.weight")) { off = 0; isgu = 1; }
+        else if (!strcmp(rest, "mlp.up_proj.weight")) { off = 4096; isgu = 1; }
+        if (off >= 0) {
+            uint16_t* dst = isgu ? y->wgu_t : y->wqkv_t; const int N = isgu ? 8192 : 3072;
+            for (int n = 0; n < rows; ++n) for (int k = 0; k < cols; ++k) dst[(size_t)k * N + off + n] = data[(size_t)n * cols + k];
+            return 0;
+        }
+        if (!strcmp(rest, "self_attn.o_proj.weight")) { y->wo_t = dup_t(data, rows, cols); return 0; }
+        if (!strcmp(rest, "mlp.down_proj.weight")) { y->wd_t = dup_t(data, rows, cols); return 0; }
+        if (!strcmp(rest, "input_layernorm.weight")) { y->ln1 = dup(data, T3_D); return 0; }
+        if (!strcmp(rest, "post_attention_layernorm.weight")) { y->ln2 = dup(data, T3_D); return 0; }
+        return -1;
+    }
+    if (!strcmp(name, "tfmr.norm.weight")) { m->norm = dup(data, T3_D); return 0; }
+    if (!strcmp(name, "text_emb.weight")) { m->text_emb = dup(data, (size_t)rows * cols); return 0; }
+    if (!strcmp(name, "speech_emb.weight")) { m->speech_emb = dup(data, (size_t)rows * cols); return 0; }
+    if (!strcmp(name, "text_pos_emb.emb.weight")) { m->text_pos = dup(data, (size_t)rows * cols); return 0; }
+    if (!strcmp(name, "speech_pos_emb.emb.weight")) { m->speech_pos = dup(data, (size_t)rows * cols); return 0; }
+    if (!strcmp(name, "speech_head.weight")) { m->head_t = dup_t(data, rows, cols); return 0; }
+    return -1;
+}
+
+void orc_destroy(OrcModel* m) {
+    for (int i = 0; i < m->n_layers; ++i) {
+        OrcLayer* y = &m->layers[i];
+        free(y->wqkv_t); free(y->wo_t); free(y->wgu_t); free(y->wd_t); free(y->ln1); free(y->ln2);
+    }
+    free(m->layers); free(m->norm); free(m->text_emb); free(m->speech_emb); free(m->text_pos);
+    free(m->speech_pos); free(m->head_t); free(m->cos_t); free(m->sin_t); free(m->kv); free(m);
+}
+
+static inline uint16_t* kv_at(OrcModel* m, int stream, int layer, int pos) {
+    return m->kv + ((((size_t)stream * m->n_layers + layer) * m->max_pos + pos) * 2) * T3_D;
+}
+
+/* Unified step over a set of rows (prefill rows and decode rows are the same thing):
+ * h [rows][1024] bf16 residual stream in/out; row r belongs to stream row_stream[r] at position
+ * row_pos[r]; all KV for positions < row_pos[r] of that stream must be in the cache or in this call.
+ * If tap_layer >= 0, the residual stream after that many layers is copied to tap.                */
+void orc_forward_rows(OrcModel* m, uint16_t* h, const int* row_stream, const int* row_pos, int rows,
+                      int tap_layer, uint16_t* tap) {
+    uint16_t* xn = (uint16_t*)malloc((size_t)rows * T3_D * 2);
+    float* f = (float*)malloc((size_t)rows * 8192 * sizeof(float));
+    uint16_t* qkv = (uint16_t*)malloc((size_t)rows * 3072 * 2);
+    uint16_t* att = (uint16_t*)malloc((size_t)rows * T3_D * 2);
+    uint16_t* act = (uint16_t*)malloc((size_t)rows * T3_F * 2);
+    for (int L = 0; L < m->n_layers; ++L) {
+        if (tap_layer == L && tap) memcpy(tap, h, (size_t)rows * T3_D * 2);
+        OrcLayer* y = &m->layers[L];
+        orc_rmsnorm(h, y->ln1, xn, rows);
+        orc_gemm(xn, y->wqkv_t, rows, T3_D, 3072, f);
+        for (size_t i = 0; i < (size_t)rows * 3072; ++i) qkv[i] = f2bf(f[i]);
+        for (int r = 0; r < rows; ++r) {
+            uint16_t* q = qkv + (size_t)r * 3072;
+            const float* c = m->cos_t + row_pos[r] * 32; const float* s = m->sin_t + row_pos[r] * 32;
+            for (int hh = 0; hh < T3_H; ++hh) { rope_head(q + hh * 64, c, s); rope_head(q + 1024 + hh * 64, c, s); }
+            uint16_t* dst = kv_at(m, row_stream[r], L, row_pos[r]);
+            memcpy(dst, q + 1024, T3_D * 2); memcpy(dst + T3_D, q + 2048, T3_D * 2);
+        }
+#pragma omp parallel for schedule(dynamic, 4) collapse(2)
+        for (int r = 0; r < rows; ++r)
+            for (int hh = 0; hh < T3_H; ++hh) {
+                const uint16_t* base = kv_at(m, row_stream[r], L, 0);
+                orc_attn_row(qkv + (size_t)r * 3072 + hh * 64, base + hh * 64, base + T3_D + hh * 64,
+                             row_pos[r] + 1, 2 * T3_D, att + (size_t)r * T3_D + hh * 64);
+            }
+        orc_gemm(att, y->wo_t, rows, T3_D, T3_D, f);
+        for (size_t i = 0; i < (size_t)rows * T3_D; ++i) h[i] = f2bf(bf2f(h[i]) + rbf(f[i]));
+        orc_rmsnorm(h, y->ln2, xn, rows);
+        orc_gemm(xn, y->wgu_t, rows, T3_D, 8192, f);
+        for (int r = 0; r < rows; ++r)
+            for (int i = 0; i < T3_F; ++i)
+                act[(size_t)r * T3_F + i] = silu_mul(f2bf(f[(size_t)r * 8192 + i]), f2bf(f[(size_t)r * 8192 + 4096 + i]));
+        orc_gemm(act, y->wd_t, rows, T3_F, T3_D, f);
+        for (size_t i = 0; i < (size_t)rows * T3_D; ++i) h[i] = f2bf(bf2f(h[i]) + rbf(f[i]));
+    }
+    if (tap_layer == m->n_layers && tap) memcpy(tap, h, (size_t)rows * T3_D * 2);
+    free(xn); free(f); free(qkv); free(att); free(act);
+}
+
+/* final norm + speech head + CFG for one utterance.  hc/hu: residual rows of the cond / uncond
+ * stream (bf16 [1024]).  out: 8194 fp32 logits (bf16-valued).  t3.py:650-662 in bf16 arithmetic:
+ * d = bf16(lc - lu); e = bf16(cfg * d); l = bf16(lc + e).                                        */
+void orc_cfg_logits(OrcModel* m, const uint16_t* hc, const uint16_t* hu, float cfg, float* out,
+                    float* out_cond, float* out_uncond) {
+    uint16_t x[2 * T3_D], xn[2 * T3_D];
+    memcpy(x, hc, T3_D * 2); memcpy(x + T3_D, hu, T3_D * 2);
+    orc_rmsnorm(x, m->norm, xn, 2);
+    float* f = (float*)malloc(sizeof(float) * 2 * T3_V);
+    orc_gemm(xn, m->head_t, 2, T3_D, T3_V, f);
+    for (int v = 0; v < T3_V; ++v) {
+        const float lc = rbf(f[v]), lu = rbf(f[T3_V + v]);
+        const float d = rbf(lc - lu);
+        const float e = rbf(cfg * d);
+        out[v] = rbf(lc + e);
+        if (out_cond) out_cond[v] = lc;
+        if (out_uncond) out_uncond[v] = lu;
+    }
+    free(f);
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10 */
+void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* ------------------------------------------------------------------ sampler
+ * Mirrors the order of the vLLM sampler configured at tts.py:455-464: penalties -> greedy
+ * short-cut -> temperature -> min_p -> top_k -> top_p -> draw.  All probability mass
+ * arithmetic is done on integer weights w = floor(exp(l - max) * 2^32) so that sums are
+ * exact and order-free (DESIGN.md "Sampler").                                           */
+typedef struct {
+    float temperature, top_p, min_p, repetition_penalty, presence_penalty, frequency_penalty;
+    int32_t top_k;           /* <= 0: disabled */
+    int32_t max_tokens;
+    int32_t ignore_eos;
+    int32_t stop_token;      /* speech-space id, -1 none (reference: 6562 = 9062-2500, tts.py:458) */
+    uint64_t seed;
+    uint64_t uid;            /* utterance id: RNG stream key, independent of batch / sharding */
+    int32_t pos_policy;      /* 0 exact speech position, 1 literal index 0 */
+    int32_t _pad;
+} OrcSampling;
+
+int orc_sample(const float* logits_in, const uint16_t* counts /* [8194] generated-token counts */,
+               const OrcSampling* sp, uint32_t step) {
+    static float l[T3_V]; static uint64_t w[T3_V]; static uint8_t keep[T3_V];
+    for (int v = 0; v < T3_V; ++v) {
+        float x = logits_in[v];
+        if (counts[v] > 0) {
+            if (sp->repetition_penalty != 1.0f) x = (x > 0.0f) ? x / sp->repetition_penalty : x * sp->repetition_penalty;
+            x = x - sp->frequency_penalty * (float)counts[v];
+            x = x - sp->presence_penalty;
+        }
+        l[v] = x;
+    }
+    if (sp->temperature < 1e-5f) {           /* greedy: first maximum */
+        int best = 0; for (int v = 1; v < T3_V; ++v) if (l[v] > l[best]) best = v;
+        return best;
+    }
+    float mx = -INFINITY;
+    for (int v = 0; v < T3_V; ++v) { l[v] = l[v] / sp->temperature; mx = fmaxf(mx, l[v]); }
+    uint64_t wmax = 0;
+    for (int v = 0; v < T3_V; ++v) {
+        const float e = orc_expf(l[v] - mx);
+        w[v] = (uint64_t)(e * 4294967296.0f);
+        keep[v] = w[v] > 0; if (w[v] > wmax) wmax = w[v];
+    }
+    if (sp->min_p > 0.0f) {
+        const double thr = (double)sp->min_p * (double)wmax;
+        for (int v = 0; v < T3_V; ++v) if ((double)w[v] < thr) keep[v] = 0;
+    }
+    if (sp->top_k > 0 && sp->top_k < T3_V) {
+        /* k-th largest kept weight; all ties at that value stay (vLLM masks strictly-below) */
+        uint64_t lo = 0, hi = wmax;          /* largest t with count(w >= t) >= k */
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo + 1) / 2; int c = 0;
+            for (int v = 0; v < T3_V; ++v) c += keep[v] && w[v] >= mid;
+            if (c >= sp->top_k) lo = mid; else hi = mid - 1;
+        }
+        for (int v = 0; v < T3_V; ++v) if (w[v] < lo) keep[v] = 0;
+    }
+    if (sp->top_p < 1.0f) {
+        uint64_t W = 0; for (int v = 0; v < T3_V; ++v) if (keep[v]) W += w[v];
+        const uint64_t Tm = (uint64_t)((1.0 - (double)sp->top_p) * (double)W);
+        /* ascending order (w asc, idx desc): drop the longest prefix whose cumulative mass <= Tm,
+         * never the last element.  t* = largest t in [0, wmax] with sum(w < t) <= Tm.             */
+        uint64_t lo = 0, hi = wmax;
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo + 1) / 2; uint64_t s = 0;
+            for (int v = 0; v < T3_V; ++v) if (keep[v] && w[v] < mid) s += w[v];
+            if (s <= Tm) lo = mid; else hi = mid - 1;
+        }
+        uint64_t below = 0; int ties = 0;
+        for (int v = 0; v < T3_V; ++v) if (keep[v]) { if (w[v] < lo) below += w[v]; else if (w[v] == lo) ++ties; }
+        uint64_t r = (lo > 0) ? (Tm - below) / lo : (uint64_t)ties;
+        if (lo == wmax && r > (uint64_t)(ties - 1)) r = (uint64_t)(ties - 1);
+        if (r > (uint64_t)ties) r = (uint64_t)ties;
+        for (int v = T3_V - 1; v >= 0; --v) {
+            if (!keep[v]) continue;
+            if (w[v] < lo) keep[v] = 0;
+            else if (w[v] == lo && r > 0) { keep[v] = 0; --r; }
+        }
+    }
+    uint64_t Wk = 0; for (int v = 0; v < T3_V; ++v) if (keep[v]) Wk += w[v];
+    uint32_t rnd[4];
+    orc_philox(step, (uint32_t)sp->uid, (uint32_t)(sp->uid >> 32), 0, (uint32_t)sp->seed, (uint32_t)(sp->seed >> 32), rnd);
+    const uint64_t u = ((uint64_t)rnd[1] << 32) | rnd[0];
+    const uint64_t target = (uint64_t)(((unsigned __int128)u * Wk) >> 64);   /* in [0, Wk) */
+    uint64_t cum = 0; int last = 0;
+    for (int v = 0; v < T3_V; ++v) if (keep[v]) { cum += w[v]; last = v; if (cum > target) return v; }
+    return last;
+}
+
+/* ------------------------------------------------------------------ prompt embeddings  (t3.py:542-561)
+ * prompt_ids [T] = [695, x*32, 696, text ids..., 697]; cond_emb fp32 [34][1024].
+ * emb_c / emb_u: [T][1024] bf16.                                                            */
+int orc_prompt_embeds(OrcModel* m, const int32_t* prompt_ids, int T, const float* cond_emb,
+                      uint16_t* emb_c, uint16_t* emb_u) {
+    if (T < T3_COND + 1) return -1;
+    for (int i = 0; i < T3_COND; ++i)
+        for (int d = 0; d < T3_D; ++d) emb_c[i * T3_D + d] = emb_u[i * T3_D + d] = f2bf(cond_emb[i * T3_D + d]);
+    for (int i = T3_COND; i < T - 1; ++i) {
+        const int id = prompt_ids[i], j = i - T3_COND;
+        if (id < 0 || id >= m->text_vocab || j >= T3_TEXT_POS) return -2;
+        for (int d = 0; d < T3_D; ++d) {
+            emb_c[i * T3_D + d] = f2bf(bf2f(m->text_emb[(size_t)id * T3_D + d]) + bf2f(m->text_pos[(size_t)j * T3_D + d]));
+            emb_u[i * T3_D + d] = 0;                 /* t3.py:556 zeros_like(text_emb) */
+        }
+    }
+    for (int d = 0; d < T3_D; ++d)
+        emb_c[(T - 1) * T3_D + d] = emb_u[(T - 1) * T3_D + d] =
+            f2bf(bf2f(m->speech_emb[(size_t)T3_BOS * T3_D + d]) + bf2f(m->speech_pos[d]));
+    return 0;
+}
+
+/* ------------------------------------------------------------------ end-to-end generate (one utterance)
+ * Uses streams 2*slot (cond) and 2*slot+1 (uncond) of the oracle's KV cache.
+ * out_ids: speech-space ids (NOT offset by 2500).  logits_out (optional): [n][8194] post-CFG logits
+ * of every step.  Returns the number of generated tokens, <0 on error.                     */
+int orc_generate(OrcModel* m, int slot, const int32_t* prompt_ids, int T, const float* cond_emb,
+                 const OrcSampling* sp, float cfg, int max_model_len, int32_t* out_ids, float* logits_out) {
+    uint16_t* e = (uint16_t*)malloc((size_t)2 * T * T3_D * 2);
+    int rc = orc_prompt_embeds(m, prompt_ids, T, cond_emb, e, e + (size_t)T * T3_D);
+    if (rc) { free(e); return rc; }
+    int* rs = (int*)malloc(sizeof(int) * 2 * T); int* rp = (int*)malloc(sizeof(int) * 2 * T);
+    for (int i = 0; i < T; ++i) { rs[i] = 2 * slot; rp[i] = i; rs[T + i] = 2 * slot + 1; rp[T + i] = i; }
+    orc_forward_rows(m, e, rs, rp, 2 * T, -1, NULL);
+    uint16_t hc[T3_D], hu[T3_D], h2[2 * T3_D];
+    memcpy(hc, e + (size_t)(T - 1) * T3_D, T3_D * 2);
+    memcpy(hu, e + (size_t)(2 * T - 1) * T3_D, T3_D * 2);
+    free(e); free(rs); free(rp);
+    uint16_t* counts = (uint16_t*)calloc(T3_V, 2);
+    float* lg = (float*)malloc(sizeof(float) * T3_V);
+    int n = 0, limit = sp->max_tokens;
+    if (limit > max_model_len - T) limit = max_model_len - T;
+    while (n < limit) {
+        orc_cfg_logits(m, hc, hu, cfg, lg, NULL, NULL);
+        if (logits_out) memcpy(logits_out + (size_t)n * T3_V, lg, sizeof(float) * T3_V);
+        const int tok = orc_sample(lg, counts, sp, (uint32_t)n);
+        out_ids[n++] = tok;
+        if (counts[tok] < 65535) counts[tok]++;
+        if (!sp->ignore_eos && tok == sp->stop_token) break;
+        if (n >= limit) break;
+        /* decode embedding: speech_emb[tok] + speech_pos[k], k = n (exact) or 0 (literal) -- t3.py:440-480 */
+        const int k = (sp->pos_policy == 0) ? (n % T3_SPEECH_POS) : 0;
+        for (int d = 0; d < T3_D; ++d)
+            h2[d] = h2[T3_D + d] = f2bf(bf2f(m->speech_emb[(size_t)tok * T3_D + d]) + bf2f(m->speech_pos[(size_t)k * T3_D + d]));
+        int s2[2] = {2 * slot, 2 * slot + 1}, p2[2] = {T - 1 + n, T - 1 + n};
+        orc_forward_rows(m, h2, s2, p2, 2, -1, NULL);
+        memcpy(hc, h2, T3_D * 2); memcpy(hu, h2 + T3_D, T3_D * 2);
+    }
+    free(counts); free(lg);
+    return n;
+}
+
+/* Batched decode timing helper for bench.py's cpu_baseline leg: runs `steps` decode steps for
+ * `B` utterances that have already been prefetched to context length ctx (KV content = whatever is
+ * in the cache; timing only).  Returns nothing; caller times it.                            */
+void orc_decode_steps_timing(OrcModel* m, int B, int ctx, int steps) {
+    const int rows = 2 * B;
+    uint16_t* h = (uint16_t*)calloc((size_t)rows * T3_D, 2);
+    int* rs = (int*)malloc(sizeof(int) * rows); int* rp = (int*)malloc(sizeof(int) * rows);
+    float* lg = (float*)malloc(sizeof(float) * T3_V);
+    for (int s = 0; s < steps; ++s) {
+        for (int r = 0; r < rows; ++r) {
+            rs[r] = r; rp[r] = ctx + s;
+            for (int d = 0; d < T3_D; ++d) h[(size_t)r * T3_D + d] = m->speech_emb[(size_t)((r * 131 + s) % T3_V) * T3_D + d];
+        }
+        orc_forward_rows(m, h, rs, rp, rows, -1, NULL);
+        for (int b = 0; b < B; ++b) orc_cfg_logits(m, h + (size_t)(2 * b) * T3_D, h + (size_t)(2 * b + 1) * T3_D, 0.5f, lg, NULL, NULL);
+    }
+    free(h); free(rs); free(rp); free(lg);
+}
