@@ -1,0 +1,603 @@
+// T3 decode engine runtime: weight store, paged-KV block allocator, continuous-batching scheduler,
+// the per-step launch sequence, and the C ABI of include/t3_engine.h.
+//
+// What it replaces in the reference (paths relative to the reference repo): the vLLM engine
+// constructed at src/chatterbox_vllm/tts.py:150-171 and driven at tts.py:445-465, plus the model
+// plugin methods it calls (src/chatterbox_vllm/models/t3/t3.py:300-332 load_weights, :424-647
+// get_input_embeddings, :676-713 forward, :650-673 compute_logits).  The reference's per-step
+// split_prefill_decode (t3.py:340-421) has no equivalent here: the scheduler knows which rows are
+// prefill and which are decode.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "t3_kernels.h"
+
+using namespace t3;
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) return e->fail(T3_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+static thread_local std::string g_create_error;
+
+namespace {
+
+struct LayerW {
+    uint16_t *qkv = nullptr, *o = nullptr, *gu = nullptr, *down = nullptr, *ln1 = nullptr, *ln2 = nullptr;  // device, packed
+    std::vector<uint16_t> h_q, h_k, h_v, h_g, h_u;   // host staging until finalize
+    bool have_o = false, have_d = false;
+};
+
+enum ReqState { WAITING = 0, PREFILL = 1, DECODE = 2, FINISHED = 3 };
+
+struct Request {
+    int64_t id;
+    std::vector<int32_t> prompt;
+    std::vector<float> cond;
+    T3Sampling sp;
+    int state = WAITING, slot = -1, n_prefilled = 0, finish_reason = 0, limit = 0;
+    std::vector<int32_t> out;         // speech-space ids
+    std::vector<int> blocks[2];
+};
+
+enum KClass { K_QKV, K_O, K_GU, K_DOWN, K_HEAD, K_ATTN, K_NORM, K_ROPE, K_EMBED, K_SAMPLE, K_COUNT };
+static const char* kclass_names[K_COUNT] = {"gemm_qkv", "gemm_o", "gemm_gateup", "gemm_down", "gemm_head",
+                                            "attention", "rmsnorm", "rope_kv", "embed", "sampler"};
+
+}  // namespace
+
+struct T3Engine {
+    T3EngineConfig cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    bool finalized = false;
+    int max_blocks = 0;        // per stream
+    int64_t n_blocks = 0;      // pool
+    int rmax = 0;              // row budget per step
+
+    // weights (device)
+    std::vector<LayerW> layers;
+    uint16_t *norm = nullptr, *text_emb = nullptr, *speech_emb = nullptr, *text_pos = nullptr, *speech_pos = nullptr, *head = nullptr;
+    bool have[6] = {false, false, false, false, false, false};
+    float *cos_t = nullptr, *sin_t = nullptr;
+    int64_t weight_bytes = 0;
+
+    // KV pool + tables
+    uint16_t* kv = nullptr;
+    std::vector<int> free_blocks;
+    int* d_block_table = nullptr;
+    std::vector<int> h_block_table;
+
+    // activations
+    uint16_t *h = nullptr, *xn = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *act = nullptr, *xlast = nullptr, *logits = nullptr;
+    float* d_cond = nullptr;
+    uint16_t* d_counts = nullptr;
+    T3Sampling* d_sp = nullptr;
+    float* d_dbg = nullptr;
+
+    // per-step metadata: one pinned host block mirrored by one device block
+    struct Meta { int* row_stream; int* row_pos; int4* desc; int* sel_rows; int4* sel; int* out_tok; };
+    char *h_meta = nullptr, *d_meta = nullptr;
+    size_t meta_bytes = 0;
+    Meta hm{}, dm{};
+    int* h_out_tok = nullptr;
+
+    // scheduler
+    std::unordered_map<int64_t, Request> reqs;
+    std::deque<int64_t> waiting;
+    std::vector<int64_t> slot_req;     // slot -> req id or -1
+    std::vector<int64_t> running;      // admission order
+
+    // stats / profiling
+    T3Stats st{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pev[K_COUNT];
+    size_t pev_used[K_COUNT] = {0};
+    double k_ms[K_COUNT] = {0};
+    int64_t k_n[K_COUNT] = {0};
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+    // algorithmic weight bytes streamed once per step (SURVEY.md 8(d) "W"): bf16 backbone incl. norms + speech head
+    double weight_bytes_for_step() const {
+        const double per_layer = (4.0 * D * D + 3.0 * F * D + 2.0 * D) * 2.0;
+        return cfg.n_layers * per_layer + D * 2.0 + (double)V * D * 2.0;
+    }
+};
+
+static int fail_create(int code, const std::string& m) { g_create_error = m; return code; }
+
+// ------------------------------------------------------------------------------------------------
+extern "C" const char* t3_last_error(T3Handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int t3_create(const T3EngineConfig* cfg, T3Handle* out) {
+    if (!cfg || !out) return fail_create(T3_E_INVALID, "null argument");
+    if (cfg->n_layers <= 0 || cfg->n_layers > 256) return fail_create(T3_E_INVALID, "n_layers out of range");
+    if (cfg->max_model_len < T3_COND_ROWS + 2 || cfg->max_model_len > 8192) return fail_create(T3_E_INVALID, "max_model_len out of range [36, 8192]");
+    if (cfg->max_seqs <= 0 || cfg->max_seqs > 4096) return fail_create(T3_E_INVALID, "max_seqs out of range");
+    if (cfg->text_vocab <= 697) return fail_create(T3_E_INVALID, "text_vocab must cover the placeholder ids 695..697");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail_create(T3_E_DEVICE, "no HIP device: this engine has no CPU fallback");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail_create(T3_E_INVALID, "device_id out of range");
+    if (hipSetDevice(cfg->device_id) != hipSuccess) return fail_create(T3_E_DEVICE, "hipSetDevice failed");
+    T3Engine* e = new T3Engine();
+    e->cfg = *cfg;
+    if (e->cfg.cfg_scale != e->cfg.cfg_scale) e->cfg.cfg_scale = 0.5f;
+    e->layers.resize(cfg->n_layers);
+    e->max_blocks = (cfg->max_model_len + KV_BLOCK - 1) / KV_BLOCK;
+    e->rmax = cfg->max_batched_rows > 0 ? cfg->max_batched_rows : std::max(2048, 2 * cfg->max_seqs);
+    e->rmax = std::max(e->rmax, 2 * cfg->max_seqs);
+    e->slot_req.assign(cfg->max_seqs, -1);
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail_create(T3_E_DEVICE, "hipStreamCreate failed"); }
+    hipEventCreate(&e->ev0); hipEventCreate(&e->ev1);
+    *out = e;
+    return T3_OK;
+}
+
+static void free_dev(void* p) { if (p) (void)hipFree(p); }
+
+extern "C" int t3_destroy(T3Handle e) {
+    if (!e) return T3_E_INVALID;
+    (void)hipSetDevice(e->cfg.device_id);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto& L : e->layers) { free_dev(L.qkv); free_dev(L.o); free_dev(L.gu); free_dev(L.down); free_dev(L.ln1); free_dev(L.ln2); }
+    free_dev(e->norm); free_dev(e->text_emb); free_dev(e->speech_emb); free_dev(e->text_pos); free_dev(e->speech_pos); free_dev(e->head);
+    free_dev(e->cos_t); free_dev(e->sin_t); free_dev(e->kv); free_dev(e->d_block_table);
+    free_dev(e->h); free_dev(e->xn); free_dev(e->qkv); free_dev(e->qrot); free_dev(e->att); free_dev(e->act); free_dev(e->xlast); free_dev(e->logits);
+    free_dev(e->d_cond); free_dev(e->d_counts); free_dev(e->d_sp); free_dev(e->d_dbg); free_dev(e->d_meta);
+    if (e->h_meta) (void)hipHostFree(e->h_meta);
+    if (e->h_out_tok) (void)hipHostFree(e->h_out_tok);
+    for (int k = 0; k < K_COUNT; ++k) for (auto& p : e->pev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return T3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+static int to_host(T3Engine* e, const void* src, size_t bytes, std::vector<uint16_t>& dst) {
+    dst.resize(bytes / 2);
+    if (hipMemcpy(dst.data(), src, bytes, hipMemcpyDefault) != hipSuccess) return e->fail(T3_E_DEVICE, "hipMemcpy (weight) failed");
+    return T3_OK;
+}
+static int upload(T3Engine* e, const uint16_t* host, size_t elems, uint16_t** dev) {
+    free_dev(*dev); *dev = nullptr;
+    if (hipMalloc((void**)dev, elems * 2) != hipSuccess) return e->fail(T3_E_NOMEM, "hipMalloc (weight) failed");
+    if (hipMemcpy(*dev, host, elems * 2, hipMemcpyHostToDevice) != hipSuccess) return e->fail(T3_E_DEVICE, "hipMemcpy H2D (weight) failed");
+    e->weight_bytes += (int64_t)elems * 2;
+    return T3_OK;
+}
+static int upload_packed(T3Engine* e, const uint16_t* W, int N, int K, int Npad, uint16_t** dev) {
+    std::vector<uint16_t> p((size_t)Npad * K);
+    pack_weight(W, N, K, Npad, p.data());
+    return upload(e, p.data(), p.size(), dev);
+}
+
+extern "C" int t3_load_tensor(T3Handle e, const char* name, const void* data, int32_t rows, int32_t cols) {
+    if (!e || !name || !data) return T3_E_INVALID;
+    if (e->finalized) return e->fail(T3_E_STATE, "weights already finalized");
+    (void)hipSetDevice(e->cfg.device_id);
+    const size_t bytes = (size_t)rows * cols * 2;
+    std::vector<uint16_t> host;
+    auto need = [&](int r, int c) -> bool { return rows == r && cols == c; };
+    int L; char rest[128];
+    if (sscanf(name, "tfmr.layers.%d.%127s", &L, rest) == 2) {
+        if (L < 0 || L >= e->cfg.n_layers) return e->fail(T3_E_NOTFOUND, std::string("layer index beyond n_layers: ") + name);
+        LayerW& y = e->layers[L];
+        std::string r(rest);
+        int rc;
+        if (r == "self_attn.q_proj.weight" || r == "self_attn.k_proj.weight" || r == "self_attn.v_proj.weight") {
+            if (!need(D, D)) return e->fail(T3_E_INVALID, std::string("bad shape for ") + name);
+            auto& dst = r[10] == 'q' ? y.h_q : r[10] == 'k' ? y.h_k : y.h_v;
+            return to_host(e, data, bytes, dst);
+        }
+        if (r == "mlp.gate_proj.weight" || r == "mlp.up_proj.weight") {
+            if (!need(F, D)) return e->fail(T3_E_INVALID, std::string("bad shape for ") + name);
+            return to_host(e, data, bytes, r[4] == 'g' ? y.h_g : y.h_u);
+        }
+        if (r == "self_attn.o_proj.weight") {
+            if (!need(D, D)) return e->fail(T3_E_INVALID, std::string("bad shape for ") + name);
+            if ((rc = to_host(e, data, bytes, host))) return rc;
+            y.have_o = true; return upload_packed(e, host.data(), D, D, D, &y.o);
+        }
+        if (r == "mlp.down_proj.weight") {
+            if (!need(D, F)) return e->fail(T3_E_INVALID, std::string("bad shape for ") + name);
+            if ((rc = to_host(e, data, bytes, host))) return rc;
+            y.have_d = true; return upload_packed(e, host.data(), D, F, D, &y.down);
+        }
+        if (r == "input_layernorm.weight" || r == "post_attention_layernorm.weight") {
+            if ((size_t)rows * cols != (size_t)D) return e->fail(T3_E_INVALID, std::string("bad shape for ") + name);
+            if ((rc = to_host(e, data, bytes, host))) return rc;
+            return upload(e, host.data(), D, r[0] == 'i' ? &y.ln1 : &y.ln2);
+        }
+        return e->fail(T3_E_NOTFOUND, std::string("unknown tensor ") + name);
+    }
+    std::string n(name);
+    int rc;
+    if (n == "tfmr.norm.weight") {
+        if ((size_t)rows * cols != (size_t)D) return e->fail(T3_E_INVALID, "bad shape for tfmr.norm.weight");
+        if ((rc = to_host(e, data, bytes, host))) return rc;
+        e->have[0] = true; return upload(e, host.data(), D, &e->norm);
+    }
+    struct { const char* nm; int r, c; uint16_t** dst; int idx; } tabs[] = {
+        {"text_emb.weight", e->cfg.text_vocab, D, &e->text_emb, 1},
+        {"speech_emb.weight", V, D, &e->speech_emb, 2},
+        {"text_pos_emb.emb.weight", 2050, D, &e->text_pos, 3},
+        {"speech_pos_emb.emb.weight", 4100, D, &e->speech_pos, 4},
+    };
+    for (auto& t : tabs)
+        if (n == t.nm) {
+            if (!need(t.r, t.c)) return e->fail(T3_E_INVALID, std::string("bad shape for ") + name);
+            if ((rc = to_host(e, data, bytes, host))) return rc;
+            e->have[t.idx] = true; return upload(e, host.data(), host.size(), t.dst);
+        }
+    if (n == "speech_head.weight") {
+        if (!need(V, D)) return e->fail(T3_E_INVALID, "bad shape for speech_head.weight");
+        if ((rc = to_host(e, data, bytes, host))) return rc;
+        e->have[5] = true; return upload_packed(e, host.data(), V, D, VPAD, &e->head);
+    }
+    return e->fail(T3_E_NOTFOUND, std::string("unknown tensor ") + name);   // cond_enc.*, text_head.*, tfmr.embed_tokens.* ...
+}
+
+template <typename T>
+static int dalloc(T3Engine* e, T** p, size_t n, bool zero = false) {
+    if (hipMalloc((void**)p, n * sizeof(T)) != hipSuccess) return e->fail(T3_E_NOMEM, "hipMalloc failed (" + std::to_string(n * sizeof(T)) + " bytes)");
+    if (zero && hipMemset(*p, 0, n * sizeof(T)) != hipSuccess) return e->fail(T3_E_DEVICE, "hipMemset failed");
+    return T3_OK;
+}
+
+extern "C" int t3_finalize_weights(T3Handle e) {
+    if (!e) return T3_E_INVALID;
+    if (e->finalized) return T3_OK;
+    (void)hipSetDevice(e->cfg.device_id);
+    int rc;
+    for (int i = 0; i < 6; ++i) if (!e->have[i]) return e->fail(T3_E_STATE, "missing non-layer tensor #" + std::to_string(i));
+    for (int L = 0; L < e->cfg.n_layers; ++L) {
+        LayerW& y = e->layers[L];
+        if (y.h_q.empty() || y.h_k.empty() || y.h_v.empty() || y.h_g.empty() || y.h_u.empty() || !y.have_o || !y.have_d || !y.ln1 || !y.ln2)
+            return e->fail(T3_E_STATE, "missing tensors for layer " + std::to_string(L));
+        std::vector<uint16_t> w((size_t)QKV * D), p((size_t)QKV * D);
+        memcpy(w.data(), y.h_q.data(), (size_t)D * D * 2);
+        memcpy(w.data() + (size_t)D * D, y.h_k.data(), (size_t)D * D * 2);
+        memcpy(w.data() + (size_t)2 * D * D, y.h_v.data(), (size_t)D * D * 2);
+        pack_weight(w.data(), QKV, D, QKV, p.data());
+        if ((rc = upload(e, p.data(), p.size(), &y.qkv))) return rc;
+        std::vector<uint16_t> g((size_t)2 * F * D);
+        pack_gate_up(y.h_g.data(), y.h_u.data(), F, D, g.data());
+        if ((rc = upload(e, g.data(), g.size(), &y.gu))) return rc;
+        y.h_q.clear(); y.h_k.clear(); y.h_v.clear(); y.h_g.clear(); y.h_u.clear();
+        y.h_q.shrink_to_fit(); y.h_k.shrink_to_fit(); y.h_v.shrink_to_fit(); y.h_g.shrink_to_fit(); y.h_u.shrink_to_fit();
+    }
+    // RoPE tables
+    {
+        const int mp = e->cfg.max_model_len;
+        std::vector<float> c((size_t)mp * 32), s((size_t)mp * 32);
+        rope_tables(mp, c.data(), s.data());
+        if ((rc = dalloc(e, &e->cos_t, c.size()))) return rc;
+        if ((rc = dalloc(e, &e->sin_t, s.size()))) return rc;
+        HIP_TRY(hipMemcpy(e->cos_t, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->sin_t, s.data(), s.size() * 4, hipMemcpyHostToDevice));
+    }
+    // activations
+    const size_t R = (size_t)e->rmax, S = (size_t)e->cfg.max_seqs;
+    if ((rc = dalloc(e, &e->h, R * D, true))) return rc;
+    if ((rc = dalloc(e, &e->xn, R * D, true))) return rc;
+    if ((rc = dalloc(e, &e->qkv, R * QKV, true))) return rc;
+    if ((rc = dalloc(e, &e->qrot, R * D, true))) return rc;
+    if ((rc = dalloc(e, &e->att, R * D, true))) return rc;
+    if ((rc = dalloc(e, &e->act, R * F, true))) return rc;
+    if ((rc = dalloc(e, &e->xlast, 2 * S * D, true))) return rc;
+    if ((rc = dalloc(e, &e->logits, 2 * S * VPAD, true))) return rc;
+    if ((rc = dalloc(e, &e->d_cond, S * T3_COND_ROWS * D, true))) return rc;
+    if ((rc = dalloc(e, &e->d_counts, S * VPAD, true))) return rc;
+    if ((rc = dalloc(e, &e->d_sp, S, true))) return rc;
+    if (e->cfg.debug_logits && (rc = dalloc(e, &e->d_dbg, S * V, true))) return rc;
+    if ((rc = dalloc(e, &e->d_block_table, 2 * S * e->max_blocks, true))) return rc;
+    e->h_block_table.assign(2 * S * e->max_blocks, 0);
+    // metadata block
+    {
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_rs = carve(R * 4), o_rp = carve(R * 4), o_desc = carve(R * 16), o_selr = carve(2 * S * 4), o_sel = carve(S * 16);
+        e->meta_bytes = off;
+        HIP_TRY(hipHostMalloc((void**)&e->h_meta, e->meta_bytes, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void**)&e->d_meta, e->meta_bytes));
+        auto fill = [&](T3Engine::Meta& m, char* base) {
+            m.row_stream = (int*)(base + o_rs); m.row_pos = (int*)(base + o_rp); m.desc = (int4*)(base + o_desc);
+            m.sel_rows = (int*)(base + o_selr); m.sel = (int4*)(base + o_sel); m.out_tok = nullptr;
+        };
+        fill(e->hm, e->h_meta); fill(e->dm, e->d_meta);
+        int* dtok = nullptr;
+        if ((rc = dalloc(e, &dtok, S, true))) return rc;
+        e->dm.out_tok = dtok;
+        HIP_TRY(hipHostMalloc((void**)&e->h_out_tok, S * 4, hipHostMallocDefault));
+    }
+    // KV pool
+    {
+        const size_t per_block = (size_t)e->cfg.n_layers * KV_BLOCK_ELEMS * 2;   // bytes
+        int64_t bytes = e->cfg.kv_bytes;
+        const int64_t want_all = (int64_t)2 * S * e->max_blocks * per_block;       // every slot at full length
+        if (bytes <= 0) {
+            size_t fr = 0, tot = 0;
+            HIP_TRY(hipMemGetInfo(&fr, &tot));
+            const float util = (e->cfg.gpu_memory_utilization > 0 && e->cfg.gpu_memory_utilization <= 1) ? e->cfg.gpu_memory_utilization : 0.9f;
+            int64_t budget = (int64_t)((double)tot * util) - (int64_t)(tot - fr);
+            budget = std::min<int64_t>(budget, (int64_t)fr - ((int64_t)512 << 20));
+            bytes = std::min<int64_t>(budget, want_all);
+        }
+        e->n_blocks = bytes / (int64_t)per_block;
+        if (e->n_blocks < 2 * e->max_blocks) return e->fail(T3_E_NOMEM, "KV pool too small for even one utterance at max_model_len");
+        // layout [layer][block][kv][head][tok][64]
+        if ((rc = dalloc(e, &e->kv, (size_t)e->n_blocks * e->cfg.n_layers * KV_BLOCK_ELEMS, true))) return rc;
+        e->free_blocks.resize(e->n_blocks);
+        for (int64_t i = 0; i < e->n_blocks; ++i) e->free_blocks[i] = (int)(e->n_blocks - 1 - i);
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    e->st.kv_blocks_total = e->n_blocks; e->st.kv_blocks_free = e->n_blocks; e->st.weight_bytes = e->weight_bytes;
+    e->finalized = true;
+    return T3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// requests
+// ------------------------------------------------------------------------------------------------
+extern "C" int t3_add_request(T3Handle e, int64_t req_id, const int32_t* ids, int32_t T, const float* cond, const T3Sampling* sp) {
+    if (!e || !ids || !cond || !sp) return T3_E_INVALID;
+    if (!e->finalized) return e->fail(T3_E_STATE, "finalize_weights first");
+    if (e->reqs.count(req_id)) return e->fail(T3_E_INVALID, "duplicate request id");
+    if (T < T3_COND_ROWS + 1) return e->fail(T3_E_INVALID, "prompt shorter than the 34 conditioning rows + BOS");
+    if (T >= e->cfg.max_model_len) return e->fail(T3_E_INVALID, "prompt (" + std::to_string(T) + " tokens) does not fit max_model_len " + std::to_string(e->cfg.max_model_len));
+    if (ids[0] != 695 || ids[T3_COND_ROWS - 1] != 696 || ids[T - 1] != 697) return e->fail(T3_E_INVALID, "prompt is not in the [695, x*32, 696, text..., 697] layout (t3.py:189-200)");
+    for (int i = T3_COND_ROWS; i < T - 1; ++i)
+        if (ids[i] < 0 || ids[i] >= e->cfg.text_vocab) return e->fail(T3_E_INVALID, "text token id out of range");
+    if (T - 1 - T3_COND_ROWS > 2050) return e->fail(T3_E_INVALID, "more text tokens than learned text positions (2050)");
+    if (sp->max_tokens <= 0) return e->fail(T3_E_INVALID, "max_tokens must be positive");
+    if (!(sp->temperature >= 0.0f) || !(sp->top_p > 0.0f && sp->top_p <= 1.0f) || !(sp->min_p >= 0.0f && sp->min_p <= 1.0f) || !(sp->repetition_penalty > 0.0f))
+        return e->fail(T3_E_INVALID, "sampling parameter out of range");
+    Request r;
+    r.id = req_id; r.prompt.assign(ids, ids + T); r.cond.assign(cond, cond + (size_t)T3_COND_ROWS * D); r.sp = *sp;
+    r.limit = std::min(sp->max_tokens, e->cfg.max_model_len - T);
+    e->reqs.emplace(req_id, std::move(r));
+    e->waiting.push_back(req_id);
+    return T3_OK;
+}
+
+extern "C" int t3_num_unfinished(T3Handle e) { return e ? (int)(e->waiting.size() + e->running.size()) : 0; }
+
+static void release_slot(T3Engine* e, Request& r) {
+    for (int s = 0; s < 2; ++s) { for (int b : r.blocks[s]) e->free_blocks.push_back(b); r.blocks[s].clear(); }
+    if (r.slot >= 0) e->slot_req[r.slot] = -1;
+    r.slot = -1;
+    e->st.kv_blocks_free = (int64_t)e->free_blocks.size();
+}
+
+static int admit(T3Engine* e) {
+    bool table_dirty = false;
+    while (!e->waiting.empty()) {
+        Request& r = e->reqs[e->waiting.front()];
+        const int T = (int)r.prompt.size();
+        const int need = (T + r.limit - 1 + KV_BLOCK - 1) / KV_BLOCK;        // positions 0 .. T+limit-2
+        int slot = -1;
+        for (int s = 0; s < e->cfg.max_seqs; ++s) if (e->slot_req[s] < 0) { slot = s; break; }
+        if (slot < 0 || (int64_t)e->free_blocks.size() < 2 * (int64_t)need) break;
+        e->waiting.pop_front();
+        r.slot = slot; r.state = PREFILL; e->slot_req[slot] = r.id;
+        for (int s = 0; s < 2; ++s)
+            for (int b = 0; b < need; ++b) {
+                const int blk = e->free_blocks.back(); e->free_blocks.pop_back();
+                r.blocks[s].push_back(blk);
+                e->h_block_table[(size_t)(2 * slot + s) * e->max_blocks + b] = blk;
+            }
+        table_dirty = true;
+        HIP_TRY(hipMemcpyAsync(e->d_cond + (size_t)slot * T3_COND_ROWS * D, r.cond.data(), (size_t)T3_COND_ROWS * D * 4, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemsetAsync(e->d_counts + (size_t)slot * VPAD, 0, VPAD * 2, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->d_sp + slot, &r.sp, sizeof(T3Sampling), hipMemcpyHostToDevice, e->stream));
+        // r.cond / r.sp are kept alive in the request map until the copy is consumed (stream-ordered, pageable -> staged synchronously)
+        e->running.push_back(r.id);
+    }
+    if (table_dirty)
+        HIP_TRY(hipMemcpyAsync(e->d_block_table, e->h_block_table.data(), e->h_block_table.size() * 4, hipMemcpyHostToDevice, e->stream));
+    e->st.kv_blocks_free = (int64_t)e->free_blocks.size();
+    return T3_OK;
+}
+
+struct Prof {
+    T3Engine* e; int k; bool on; hipEvent_t a, b;
+    Prof(T3Engine* e_, int k_) : e(e_), k(k_), on(e_->profile) {
+        if (!on) return;
+        auto& v = e->pev[k]; size_t& u = e->pev_used[k];
+        if (u == v.size()) { hipEvent_t x, y; hipEventCreate(&x); hipEventCreate(&y); v.emplace_back(x, y); }
+        a = v[u].first; b = v[u].second; ++u;
+        hipEventRecord(a, e->stream);
+    }
+    ~Prof() { if (on) hipEventRecord(b, e->stream); }
+};
+
+extern "C" int t3_step(T3Handle e, T3StepResult* res) {
+    if (!e) return T3_E_INVALID;
+    if (!e->finalized) return e->fail(T3_E_STATE, "finalize_weights first");
+    (void)hipSetDevice(e->cfg.device_id);
+    T3StepResult local{}; if (!res) res = &local;
+    memset(res, 0, sizeof(*res));
+    int rc;
+    if ((rc = admit(e))) return rc;
+
+    // ---- build rows: decode rows of every running utterance, then prefill rows within the budget
+    int M = 0, n_sel = 0, n_prefill_rows = 0;
+    double sum_ctx = 0;
+    std::vector<Request*> sampled;
+    auto add_row = [&](int stream, int pos, int kind, int a, int b) {
+        e->hm.row_stream[M] = stream; e->hm.row_pos[M] = pos; e->hm.desc[M] = make_int4(kind, a, b, 0); ++M;
+    };
+    for (int64_t id : e->running) {
+        Request& r = e->reqs[id];
+        if (r.state != DECODE) continue;
+        const int T = (int)r.prompt.size(), n = (int)r.out.size();
+        const int pos = T - 1 + n, spos = r.sp.pos_policy == 0 ? (n % 4100) : 0;
+        e->hm.sel_rows[2 * n_sel] = M;     add_row(2 * r.slot, pos, EMB_SPEECH, r.out.back(), spos);
+        e->hm.sel_rows[2 * n_sel + 1] = M; add_row(2 * r.slot + 1, pos, EMB_SPEECH, r.out.back(), spos);
+        e->hm.sel[n_sel] = make_int4(r.slot, n, 0, 0);
+        sum_ctx += 2.0 * (pos + 1);
+        sampled.push_back(&r); ++n_sel;
+    }
+    const int decode_rows = M;
+    for (int64_t id : e->running) {
+        Request& r = e->reqs[id];
+        if (r.state != PREFILL) continue;
+        const int T = (int)r.prompt.size();
+        const int chunk = std::min(T - r.n_prefilled, (e->rmax - M) / 2);
+        if (chunk <= 0) break;
+        const int p0 = r.n_prefilled, p1 = p0 + chunk;
+        for (int s = 0; s < 2; ++s)
+            for (int p = p0; p < p1; ++p) {
+                if (p < T3_COND_ROWS) add_row(2 * r.slot + s, p, EMB_COND, r.slot, p);
+                else if (p < T - 1) { if (s == 0) add_row(2 * r.slot, p, EMB_TEXT, r.prompt[p], p - T3_COND_ROWS); else add_row(2 * r.slot + 1, p, EMB_ZERO, 0, 0); }
+                else add_row(2 * r.slot + s, p, EMB_SPEECH, 6561, 0);      // BOS: speech_emb[start] + speech_pos[0], t3.py:550-551
+                if (p == T - 1) e->hm.sel_rows[2 * n_sel + s] = M - 1;
+            }
+        r.n_prefilled = p1; n_prefill_rows += 2 * chunk;
+        if (p1 == T) { e->hm.sel[n_sel] = make_int4(r.slot, 0, 0, 0); sampled.push_back(&r); ++n_sel; }
+    }
+    res->n_rows = M; res->n_prefill_rows = n_prefill_rows; res->n_sampled = n_sel;
+    if (M == 0) { res->n_running = (int)e->running.size(); res->n_waiting = (int)e->waiting.size(); return T3_OK; }
+
+    HIP_TRY(hipMemcpyAsync(e->d_meta, e->h_meta, e->meta_bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    hipStream_t s = e->stream;
+    {
+        Prof p(e, K_EMBED);
+        EmbedArgs ea{e->dm.desc, e->d_cond, e->text_emb, e->text_pos, e->speech_emb, e->speech_pos, e->h, M};
+        HIP_TRY(launch_embed(ea, s));
+    }
+    const size_t layer_elems = (size_t)e->n_blocks * KV_BLOCK_ELEMS;
+    for (int L = 0; L < e->cfg.n_layers; ++L) {
+        LayerW& y = e->layers[L];
+        uint16_t* kvL = e->kv + (size_t)L * layer_elems;
+        { Prof p(e, K_NORM); HIP_TRY(launch_rmsnorm(e->h, y.ln1, e->xn, M, nullptr, s)); }
+        { Prof p(e, K_QKV); GemmArgs g{e->xn, (const uint4*)y.qkv, M, D, QKV, e->qkv, QKV}; HIP_TRY(launch_gemm(g, EPI_BF16, choose_mt(M, QKV / 16), s)); }
+        { Prof p(e, K_ROPE); RopeArgs ra{e->qkv, e->qrot, kvL, e->dm.row_stream, e->dm.row_pos, e->d_block_table, e->max_blocks, e->cos_t, e->sin_t, M}; HIP_TRY(launch_rope_kv(ra, s)); }
+        { Prof p(e, K_ATTN); AttnArgs aa{e->qrot, kvL, e->dm.row_stream, e->dm.row_pos, e->d_block_table, e->max_blocks, e->att, M, e->max_blocks}; HIP_TRY(launch_attention(aa, s)); }
+        { Prof p(e, K_O); GemmArgs g{e->att, (const uint4*)y.o, M, D, D, e->h, D}; HIP_TRY(launch_gemm(g, EPI_RESID, choose_mt(M, D / 16), s)); }
+        { Prof p(e, K_NORM); HIP_TRY(launch_rmsnorm(e->h, y.ln2, e->xn, M, nullptr, s)); }
+        { Prof p(e, K_GU); GemmArgs g{e->xn, (const uint4*)y.gu, M, D, F, e->act, F}; HIP_TRY(launch_gemm(g, EPI_SILU, choose_mt(M, F / 16), s)); }
+        { Prof p(e, K_DOWN); GemmArgs g{e->act, (const uint4*)y.down, M, F, D, e->h, D}; HIP_TRY(launch_gemm(g, EPI_RESID, choose_mt(M, D / 16), s)); }
+    }
+    if (n_sel > 0) {
+        { Prof p(e, K_NORM); HIP_TRY(launch_rmsnorm(e->h, e->norm, e->xlast, 2 * n_sel, e->dm.sel_rows, s)); }
+        { Prof p(e, K_HEAD); GemmArgs g{e->xlast, (const uint4*)e->head, 2 * n_sel, D, V, e->logits, VPAD}; HIP_TRY(launch_gemm(g, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16), s)); }
+        { Prof p(e, K_SAMPLE); SampleArgs sa{e->logits, VPAD, e->dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, e->dm.out_tok, e->d_dbg, n_sel}; HIP_TRY(launch_sampler(sa, s)); }
+        HIP_TRY(hipMemcpyAsync(e->h_out_tok, e->dm.out_tok, (size_t)n_sel * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipEventRecord(e->ev1, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    float ms = 0; (void)hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    const bool decode_only = (n_prefill_rows == 0);
+    e->st.steps++; e->st.gpu_ms_total += ms; e->st.prefill_rows += n_prefill_rows; e->st.decode_rows += decode_rows;
+    if (decode_only) {
+        e->st.decode_steps++; e->st.gpu_ms_decode += ms; e->st.sum_ctx_decode += sum_ctx;
+        // W + KV read + KV write + embedding rows, scaled to n_layers
+        const double per_tok_stream = 2.0 * e->cfg.n_layers * H * HD * 2;
+        e->st.algo_bytes_decode += (double)e->weight_bytes_for_step() + per_tok_stream * sum_ctx + per_tok_stream * decode_rows + (decode_rows / 2) * 4096.0;
+    }
+    if (e->profile) {
+        for (int k = 0; k < K_COUNT; ++k) {
+            if (decode_only)
+                for (size_t i = 0; i < e->pev_used[k]; ++i) { float t = 0; (void)hipEventElapsedTime(&t, e->pev[k][i].first, e->pev[k][i].second); e->k_ms[k] += t; e->k_n[k]++; }
+            e->pev_used[k] = 0;
+        }
+    }
+    // ---- host bookkeeping
+    for (int i = 0; i < n_sel; ++i) {
+        Request& r = *sampled[i];
+        const int tok = e->h_out_tok[i];
+        r.out.push_back(tok); r.state = DECODE; e->st.tokens_generated++;
+        int fin = 0;
+        if (!r.sp.ignore_eos && tok == r.sp.stop_token) fin = 1;
+        else if ((int)r.out.size() >= r.limit) fin = 2;
+        if (fin) {
+            r.state = FINISHED; r.finish_reason = fin;
+            if (res->n_finished < 64) res->finished_ids[res->n_finished] = r.id;
+            res->n_finished++;
+            release_slot(e, r);
+        }
+    }
+    if (res->n_finished) e->running.erase(std::remove_if(e->running.begin(), e->running.end(), [&](int64_t id) { return e->reqs[id].state == FINISHED; }), e->running.end());
+    res->n_running = (int)e->running.size(); res->n_waiting = (int)e->waiting.size();
+    return T3_OK;
+}
+
+extern "C" int t3_run_until_done(T3Handle e) {
+    if (!e) return T3_E_INVALID;
+    T3StepResult r;
+    while (t3_num_unfinished(e) > 0) {
+        int rc = t3_step(e, &r);
+        if (rc) return rc;
+        if (r.n_rows == 0) return e->fail(T3_E_NOMEM, "scheduler stalled: waiting requests cannot be admitted");
+    }
+    return T3_OK;
+}
+
+extern "C" int t3_get_output(T3Handle e, int64_t req_id, int32_t* ids, int32_t* n, int32_t* finish_reason) {
+    if (!e || !n) return T3_E_INVALID;
+    auto it = e->reqs.find(req_id);
+    if (it == e->reqs.end()) return e->fail(T3_E_NOTFOUND, "unknown request id");
+    const Request& r = it->second;
+    const int have = (int)r.out.size();
+    if (ids) { const int m = std::min(have, *n); for (int i = 0; i < m; ++i) ids[i] = r.out[i] + T3_SPEECH_TOKEN_OFFSET; }
+    *n = have;
+    if (finish_reason) *finish_reason = r.finish_reason;
+    return T3_OK;
+}
+
+extern "C" int t3_release_request(T3Handle e, int64_t req_id) {
+    if (!e) return T3_E_INVALID;
+    auto it = e->reqs.find(req_id);
+    if (it == e->reqs.end()) return e->fail(T3_E_NOTFOUND, "unknown request id");
+    if (it->second.state != FINISHED) return e->fail(T3_E_STATE, "request still running");
+    e->reqs.erase(it);
+    return T3_OK;
+}
+
+extern "C" int t3_debug_logits(T3Handle e, int64_t req_id, float* out) {
+    if (!e || !out) return T3_E_INVALID;
+    if (!e->d_dbg) return e->fail(T3_E_STATE, "engine was created without debug_logits");
+    auto it = e->reqs.find(req_id);
+    if (it == e->reqs.end()) return e->fail(T3_E_NOTFOUND, "unknown request id");
+    int slot = it->second.slot;
+    if (slot < 0) return e->fail(T3_E_STATE, "request holds no slot (finished): read logits before the finishing step or use max_tokens+1");
+    HIP_TRY(hipMemcpy(out, e->d_dbg + (size_t)slot * V, (size_t)V * 4, hipMemcpyDeviceToHost));
+    return T3_OK;
+}
+
+extern "C" int t3_stats(T3Handle e, T3Stats* out) { if (!e || !out) return T3_E_INVALID; *out = e->st; return T3_OK; }
+extern "C" int t3_reset_stats(T3Handle e) {
+    if (!e) return T3_E_INVALID;
+    const int64_t bt = e->st.kv_blocks_total, bf = e->st.kv_blocks_free, wb = e->st.weight_bytes;
+    e->st = T3Stats{}; e->st.kv_blocks_total = bt; e->st.kv_blocks_free = bf; e->st.weight_bytes = wb;
+    for (int k = 0; k < K_COUNT; ++k) { e->k_ms[k] = 0; e->k_n[k] = 0; }
+    return T3_OK;
+}
+extern "C" int t3_set_profile(T3Handle e, int32_t on) { if (!e) return T3_E_INVALID; e->profile = on != 0; return T3_OK; }
+extern "C" int t3_kernel_ms(T3Handle e, const char* name, double* avg_ms, int64_t* launches) {
+    if (!e || !name) return T3_E_INVALID;
+    for (int k = 0; k < K_COUNT; ++k)
+        if (!strcmp(name, kclass_names[k])) {
+            if (avg_ms) *avg_ms = e->k_n[k] ? e->k_ms[k] / (double)e->k_n[k] : 0.0;
+            if (launches) *launches = e->k_n[k];
+            return T3_OK;
+        }
+    return e->fail(T3_E_NOTFOUND, "unknown kernel class");
+}

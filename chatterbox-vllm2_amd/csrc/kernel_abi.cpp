@@ -1,0 +1,135 @@
+// Kernel-level entry points of include/t3_engine.h (t3k_*): host buffers in, host buffers out.
+// They run exactly the kernels the engine runs, so the parity tests can check each kernel against the
+// oracle's function of the same name through the C ABI.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "t3_kernels.h"
+
+using namespace t3;
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes, bool zero = false) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e == hipSuccess && zero) e = hipMemset(p, 0, bytes ? bytes : 16);
+        return e;
+    }
+    hipError_t from(const void* h, size_t bytes) {
+        hipError_t e = alloc(bytes);
+        if (e == hipSuccess && bytes) e = hipMemcpy(p, h, bytes, hipMemcpyHostToDevice);
+        return e;
+    }
+    template <typename T> T* as() { return reinterpret_cast<T*>(p); }
+};
+bool have_device() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0; }
+}  // namespace
+
+#define K_TRY(expr) do { if ((expr) != hipSuccess) return T3_E_DEVICE; } while (0)
+
+extern "C" int t3k_gemm(const void* x, const void* w, int32_t M, int32_t K, int32_t N, float* out, int32_t mt) {
+    if (!x || !w || !out || M <= 0 || N <= 0 || K % 128) return T3_E_INVALID;
+    if (!have_device()) return T3_E_DEVICE;
+    const int Npad = (N + 15) / 16 * 16;
+    std::vector<uint16_t> packed((size_t)Npad * K);
+    pack_weight((const uint16_t*)w, N, K, Npad, packed.data());
+    DevBuf dx, dw, dout;
+    K_TRY(dx.from(x, (size_t)M * K * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * N * 4, true));
+    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, K, N, dout.p, N};
+    K_TRY(launch_gemm(a, EPI_F32, mt > 0 ? mt : choose_mt(M, Npad / 16), nullptr));
+    K_TRY(hipDeviceSynchronize());
+    K_TRY(hipMemcpy(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    return T3_OK;
+}
+
+extern "C" int t3k_rmsnorm(const void* x, const void* w, void* y, int32_t rows) {
+    if (!x || !w || !y || rows <= 0) return T3_E_INVALID;
+    if (!have_device()) return T3_E_DEVICE;
+    DevBuf dx, dw, dy;
+    K_TRY(dx.from(x, (size_t)rows * D * 2)); K_TRY(dw.from(w, D * 2)); K_TRY(dy.alloc((size_t)rows * D * 2));
+    K_TRY(launch_rmsnorm(dx.as<uint16_t>(), dw.as<uint16_t>(), dy.as<uint16_t>(), rows, nullptr, nullptr));
+    K_TRY(hipDeviceSynchronize());
+    K_TRY(hipMemcpy(y, dy.p, (size_t)rows * D * 2, hipMemcpyDeviceToHost));
+    return T3_OK;
+}
+
+extern "C" int t3k_silu_mul_gemm(const void* x, const void* wg, const void* wu, int32_t M, int32_t Fd, void* out) {
+    if (!x || !wg || !wu || !out || M <= 0 || Fd <= 0 || Fd % 16) return T3_E_INVALID;
+    if (!have_device()) return T3_E_DEVICE;
+    std::vector<uint16_t> packed((size_t)2 * Fd * D);
+    pack_gate_up((const uint16_t*)wg, (const uint16_t*)wu, Fd, D, packed.data());
+    DevBuf dx, dw, dout;
+    K_TRY(dx.from(x, (size_t)M * D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * Fd * 2, true));
+    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, D, Fd, dout.p, Fd};
+    K_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, Fd / 16), nullptr));
+    K_TRY(hipDeviceSynchronize());
+    K_TRY(hipMemcpy(out, dout.p, (size_t)M * Fd * 2, hipMemcpyDeviceToHost));
+    return T3_OK;
+}
+
+extern "C" int t3k_rope_attention(const void* qkv, const int32_t* row_stream, const int32_t* row_pos, int32_t rows,
+                                  int32_t n_streams, int32_t max_pos, void* out) {
+    if (!qkv || !row_stream || !row_pos || !out || rows <= 0 || n_streams <= 0 || max_pos <= 0) return T3_E_INVALID;
+    if (!have_device()) return T3_E_DEVICE;
+    for (int r = 0; r < rows; ++r)
+        if (row_stream[r] < 0 || row_stream[r] >= n_streams || row_pos[r] < 0 || row_pos[r] >= max_pos) return T3_E_INVALID;
+    const int max_blocks = (max_pos + KV_BLOCK - 1) / KV_BLOCK;
+    // a deliberately scrambled block table, so that the test exercises the paging
+    std::vector<int> table((size_t)n_streams * max_blocks);
+    const int nb = n_streams * max_blocks;
+    for (int i = 0; i < nb; ++i) table[i] = (int)(((long)i * 7919 + 13) % nb);
+    {   // make it a permutation: 7919 is coprime with nb unless nb is a multiple of 7919
+        std::vector<char> seen(nb, 0); bool ok = true;
+        for (int i = 0; i < nb; ++i) { if (seen[table[i]]) ok = false; seen[table[i]] = 1; }
+        if (!ok) for (int i = 0; i < nb; ++i) table[i] = nb - 1 - i;
+    }
+    std::vector<float> c((size_t)max_pos * 32), s((size_t)max_pos * 32);
+    rope_tables(max_pos, c.data(), s.data());
+    DevBuf dqkv, drs, drp, dbt, dc, ds, dq, dkv, dout;
+    K_TRY(dqkv.from(qkv, (size_t)rows * QKV * 2)); K_TRY(drs.from(row_stream, rows * 4)); K_TRY(drp.from(row_pos, rows * 4));
+    K_TRY(dbt.from(table.data(), table.size() * 4)); K_TRY(dc.from(c.data(), c.size() * 4)); K_TRY(ds.from(s.data(), s.size() * 4));
+    K_TRY(dq.alloc((size_t)rows * D * 2)); K_TRY(dkv.alloc((size_t)nb * KV_BLOCK_ELEMS * 2, true)); K_TRY(dout.alloc((size_t)rows * D * 2, true));
+    RopeArgs ra{dqkv.as<uint16_t>(), dq.as<uint16_t>(), dkv.as<uint16_t>(), drs.as<int>(), drp.as<int>(), dbt.as<int>(), max_blocks, dc.as<float>(), ds.as<float>(), rows};
+    K_TRY(launch_rope_kv(ra, nullptr));
+    AttnArgs aa{dq.as<uint16_t>(), dkv.as<uint16_t>(), drs.as<int>(), drp.as<int>(), dbt.as<int>(), max_blocks, dout.as<uint16_t>(), rows, max_blocks};
+    K_TRY(launch_attention(aa, nullptr));
+    K_TRY(hipDeviceSynchronize());
+    K_TRY(hipMemcpy(out, dout.p, (size_t)rows * D * 2, hipMemcpyDeviceToHost));
+    return T3_OK;
+}
+
+extern "C" int t3k_sample(const void* logits2, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg, uint32_t step,
+                          int32_t* token_out, float* logits_out) {
+    if (!logits2 || !counts || !sp || !token_out || ldl < V) return T3_E_INVALID;
+    if (!have_device()) return T3_E_DEVICE;
+    std::vector<uint16_t> cpad(VPAD, 0);
+    memcpy(cpad.data(), counts, V * 2);
+    const int4 sel = make_int4(0, (int)step, 0, 0);
+    DevBuf dl, dc, dsp, dsel, dtok, ddbg;
+    K_TRY(dl.from(logits2, (size_t)2 * ldl * 2)); K_TRY(dc.from(cpad.data(), VPAD * 2)); K_TRY(dsp.from(sp, sizeof(T3Sampling)));
+    K_TRY(dsel.from(&sel, sizeof(sel))); K_TRY(dtok.alloc(4, true)); K_TRY(ddbg.alloc((size_t)V * 4, true));
+    SampleArgs sa{dl.as<uint16_t>(), ldl, dsel.as<int4>(), dc.as<uint16_t>(), dsp.as<T3Sampling>(), cfg, dtok.as<int>(), ddbg.as<float>(), 1};
+    K_TRY(launch_sampler(sa, nullptr));
+    K_TRY(hipDeviceSynchronize());
+    K_TRY(hipMemcpy(token_out, dtok.p, 4, hipMemcpyDeviceToHost));
+    K_TRY(hipMemcpy(cpad.data(), dc.p, VPAD * 2, hipMemcpyDeviceToHost));
+    memcpy(counts, cpad.data(), V * 2);
+    if (logits_out) K_TRY(hipMemcpy(logits_out, ddbg.p, (size_t)V * 4, hipMemcpyDeviceToHost));
+    return T3_OK;
+}
+
+extern "C" int t3k_expf(const float* x, float* y, int32_t n) {
+    if (!x || !y || n <= 0) return T3_E_INVALID;
+    if (!have_device()) return T3_E_DEVICE;
+    DevBuf dx, dy;
+    K_TRY(dx.from(x, (size_t)n * 4)); K_TRY(dy.alloc((size_t)n * 4));
+    K_TRY(launch_expf(dx.as<float>(), dy.as<float>(), n, nullptr));
+    K_TRY(hipDeviceSynchronize());
+    K_TRY(hipMemcpy(y, dy.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return T3_OK;
+}

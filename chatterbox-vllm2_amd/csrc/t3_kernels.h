@@ -1,0 +1,82 @@
+// Internal launcher interface between engine.cpp and t3_kernels.hip (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/t3_engine.h"
+
+namespace t3 {
+
+constexpr int D = 1024, H = 16, HD = 64, F = 4096, V = 8194, VPAD = 8208, QKV = 3072;
+constexpr int KV_BLOCK = 64;                       // tokens per KV block == attention chunk
+constexpr int KV_BLOCK_ELEMS = 2 * H * KV_BLOCK * HD;  // per layer per block: K then V, [kv][head][tok][64]
+
+enum GemmEpi { EPI_F32 = 0, EPI_BF16 = 1, EPI_RESID = 2, EPI_SILU = 3 };
+
+struct GemmArgs {
+    const uint16_t* X;   // [M][K] bf16 row-major
+    const uint4* Wp;     // packed weight, see pack_weight()
+    int M, K, N;         // N = number of valid output columns (EPI_SILU: F)
+    void* out;           // EPI_F32: float [M][ldo]; else bf16 [M][ldo]; EPI_RESID: residual stream, updated in place
+    int ldo;
+};
+
+// Host-side packing of a [N][K] bf16 matrix into MFMA-B-operand order:
+// out[((nt*KB + kb)*64 + lane)*8 + j] = W[nt*16 + (lane&15)][kb*32 + 8*(lane>>4) + j], rows >= N are zero.
+void pack_weight(const uint16_t* W, int N, int K, int Npad, uint16_t* out);
+// gate/up interleave: packed tile 2t = gate tile t, 2t+1 = up tile t.
+void pack_gate_up(const uint16_t* Wg, const uint16_t* Wu, int Fdim, int K, uint16_t* out);
+
+int choose_mt(int M, int ntiles_x);
+hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s);
+hipError_t launch_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, const int* gather, hipStream_t s);
+
+struct EmbedArgs {
+    const int4* desc;          // per row {kind, a, b, c}
+    const float* cond;         // [max_seqs][34][1024] fp32
+    const uint16_t *text_emb, *text_pos, *speech_emb, *speech_pos;
+    uint16_t* h;               // [rows][1024]
+    int rows;
+};
+enum EmbedKind { EMB_COND = 0 /*a=slot,b=idx*/, EMB_TEXT = 1 /*a=id,b=pos*/, EMB_ZERO = 2, EMB_SPEECH = 3 /*a=id,b=pos*/ };
+hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
+
+struct RopeArgs {
+    const uint16_t* qkv;       // [rows][3072]
+    uint16_t* q_out;           // [rows][1024]
+    uint16_t* kv_layer;        // pool + layer*n_blocks*KV_BLOCK_ELEMS
+    const int *row_stream, *row_pos, *block_table;
+    int max_blocks;            // block_table row stride
+    const float *cos_t, *sin_t;  // [max_pos][32]
+    int rows;
+};
+hipError_t launch_rope_kv(const RopeArgs& a, hipStream_t s);
+
+struct AttnArgs {
+    const uint16_t* q;         // [rows][1024] rotated
+    const uint16_t* kv_layer;
+    const int *row_stream, *row_pos, *block_table;
+    int max_blocks;
+    uint16_t* out;             // [rows][1024]
+    int rows;
+    int max_chunks;            // LDS sizing: ceil(max_model_len/64)
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+struct SampleArgs {
+    const uint16_t* logits;    // [2*n][ldl] bf16: row 2i cond, 2i+1 uncond
+    int ldl;
+    const int4* sel;           // per sampled utterance {slot, step, 0, 0}
+    uint16_t* counts;          // [max_seqs][VPAD]
+    const T3Sampling* sp;      // [max_seqs], indexed by slot
+    float cfg;
+    int* out_tok;              // [n]
+    float* dbg;                // nullable: [max_seqs][V]
+    int n;
+};
+hipError_t launch_sampler(const SampleArgs& a, hipStream_t s);
+hipError_t launch_expf(const float* x, float* y, int n, hipStream_t s);
+
+void rope_tables(int max_pos, float* cos_t, float* sin_t);   // host, llama3 scaling, bf16-valued
+
+}  // namespace t3

@@ -1,0 +1,703 @@
+// HIP kernels of the T3 decode engine for gfx950 (MI355X, CDNA4).  wave = 64 lanes.
+//
+// Every floating-point rounding point and summation order in this file is part of the numerics
+// contract written down in DESIGN.md ("Numerics contract"); the contract is what makes the emitted
+// token ids bit-identical to the CPU restatement of the reference semantics.  Compile with
+// -ffp-contract=off: every fused multiply-add below is an explicit __builtin_fmaf.
+//
+// Reference semantics being implemented (paths relative to the reference repo):
+//   embed ............ src/chatterbox_vllm/models/t3/t3.py:440-486, 542-561
+//   Llama block ...... t3.py:696-713 -> vllm LlamaModel, hyper-parameters t3-model/config.json:1-33
+//   CFG logits ....... t3.py:650-673
+//   sampler .......... vllm SamplingParams as configured at src/chatterbox_vllm/tts.py:455-464
+#include "t3_kernels.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace t3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// scalar helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+// fp32 -> bf16 round-to-nearest-even, NaN stays quiet NaN
+__device__ __forceinline__ uint32_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float rbf(float f) { return __uint_as_float(f2bf(f) << 16); }
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+
+// element j (0..7) of a 16-byte vector of 8 bf16, as fp32
+template <int J>
+__device__ __forceinline__ float elem(const uint4& v) {
+    const uint32_t w = (J >> 1) == 0 ? v.x : (J >> 1) == 1 ? v.y : (J >> 1) == 2 ? v.z : v.w;
+    return (J & 1) ? bf_hi(w) : bf_lo(w);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+    f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+
+// Contract exp: Cody-Waite + degree-6 Horner; only fma / mul / round-to-nearest-even.
+__device__ __forceinline__ float t3_expf(float x) {
+    if (!(x >= -87.0f)) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    const float n = __builtin_rintf(x * 1.44269502162933349609375f);
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.428606765330187045e-06f, r);
+    float p = 1.388888922519981861e-03f;
+    p = __builtin_fmaf(p, r, 8.333333767950534821e-03f);
+    p = __builtin_fmaf(p, r, 4.166666790843009949e-02f);
+    p = __builtin_fmaf(p, r, 1.666666716337203979e-01f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    const int ni = (int)n;
+    const float s = __uint_as_float((uint32_t)(ni + 127) << 23);
+    return p * s;
+}
+
+__device__ __forceinline__ uint32_t silu_mul_bf(uint32_t g, uint32_t u) {   // bf16 bits in, bf16 bits out
+    const float gf = __uint_as_float(g << 16);
+    const float sg = rbf(gf / (1.0f + t3_expf(-gf)));
+    return f2bf(sg * __uint_as_float(u << 16));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skinny GEMM  y[m][n] = sum_k x[m][k] * W[n][k]   (x, W bf16; exact products; fp32 chains)
+//
+// Contract order: K is cut into 4 contiguous segments (one per wave of the workgroup); within a
+// segment 32-wide k-blocks ascending; within a block k = 8q + j with j outer, q inner -- exactly the
+// order in which v_mfma_f32_16x16x4_f32 (an fmaf chain over its 4 k values q = 0..3, exact fp32)
+// consumes element j of every lane's 16-byte operand fragment; result = ((p0 + p1) + p2) + p3.
+//
+// One workgroup = 4 waves = NT n-tiles of 16 columns x MT m-tiles of 16 rows.  Weights are packed so
+// that a wave's weight load is one contiguous 1 KiB (pack_weight); activations are read row-major,
+// 16 rows x 64 B per wave instruction (L2-resident, they are tiny next to the weights).
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][MT*NT][4 regs][64 lanes]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int KB = a.K >> 5, kbs = KB >> 2, kb0 = wave * kbs;
+
+    const uint4* wp[NT];
+    const uint4* xp[MT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wp[t] = a.Wp + ((size_t)(blockIdx.x * NT + t) * KB + kb0) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = (blockIdx.y * MT + i) * 16 + c;
+        m = m < a.M ? m : a.M - 1;                 // padded rows re-read the last row; their outputs are dropped
+        xp[i] = reinterpret_cast<const uint4*>(a.X + (size_t)m * a.K + kb0 * 32 + q * 8);
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 wc[NT], xc[MT], wn[NT], xn[MT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wc[t] = wp[t][0];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xc[i] = xp[i][0];
+
+    for (int kb = 0; kb < kbs; ++kb) {
+        if (kb + 1 < kbs) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wn[t] = wp[t][(kb + 1) * 64];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xn[i] = xp[i][(kb + 1) * 4];
+        }
+#define T3_MFMA_STEP(J)                                                                              \
+        {                                                                                            \
+            float bj[NT], aj[MT];                                                                    \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) bj[t] = elem<J>(wc[t]);                    \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) aj[i] = elem<J>(xc[i]);                    \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                            \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                        \
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[i], bj[t], acc[i][t], 0, 0, 0); \
+        }
+        T3_MFMA_STEP(0) T3_MFMA_STEP(1) T3_MFMA_STEP(2) T3_MFMA_STEP(3)
+        T3_MFMA_STEP(4) T3_MFMA_STEP(5) T3_MFMA_STEP(6) T3_MFMA_STEP(7)
+#undef T3_MFMA_STEP
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wc[t] = wn[t];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xc[i] = xn[i];
+    }
+
+    // cross-wave (= cross-segment) reduction in segment order
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((wave * (MT * NT) + i * NT + t) * 4 + r) * 64 + lane] = acc[i][t][r];
+    __syncthreads();
+
+    const int r = wave;                 // each wave finishes one accumulator register index
+    const int mrow = 4 * q + r, ncol = c;   // D[row = 4*(lane>>4) + reg][col = lane&15]
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = (blockIdx.y * MT + i) * 16 + mrow;
+        float v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int it = i * NT + t;
+            float s = red[((0 * (MT * NT) + it) * 4 + r) * 64 + lane];
+            s = s + red[((1 * (MT * NT) + it) * 4 + r) * 64 + lane];
+            s = s + red[((2 * (MT * NT) + it) * 4 + r) * 64 + lane];
+            s = s + red[((3 * (MT * NT) + it) * 4 + r) * 64 + lane];
+            v[t] = s;
+        }
+        if (m >= a.M) continue;
+        if constexpr (EPI == EPI_SILU) {
+            static_assert(EPI != EPI_SILU || NT == 2, "SILU epilogue needs gate/up tile pairs");
+            const int n = blockIdx.x * 16 + ncol;      // tile pair index == output tile index
+            if (n < a.N)
+                reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)silu_mul_bf(f2bf(v[0]), f2bf(v[NT - 1]));
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = (blockIdx.x * NT + t) * 16 + ncol;
+                if (n >= a.N) continue;
+                if constexpr (EPI == EPI_F32) {
+                    reinterpret_cast<float*>(a.out)[(size_t)m * a.ldo + n] = v[t];
+                } else if constexpr (EPI == EPI_BF16) {
+                    reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)f2bf(v[t]);
+                } else {   // EPI_RESID: h = bf16(h + bf16(y))
+                    uint16_t* hp = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
+                    *hp = (uint16_t)f2bf(bf2f(*hp) + rbf(v[t]));
+                }
+            }
+        }
+    }
+}
+
+int choose_mt(int M, int ntiles_x) {
+    const int mtiles = (M + 15) / 16;
+    if (const char* e = getenv("T3_GEMM_MT")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) return v; }
+    // largest MT that still leaves >= 2 workgroups per CU, never more than the rows need
+    int best = 1;
+    for (int mt = 8; mt >= 1; mt >>= 1) {
+        if (mt > 1 && mt / 2 >= mtiles) continue;
+        const long wgs = (long)ntiles_x * ((mtiles + mt - 1) / mt);
+        if (wgs >= 512 || mt == 1) { best = mt; break; }
+    }
+    return best;
+}
+
+template <int MT, int NT, int EPI>
+static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
+    const int ntiles = (a.N + 15) / 16;           // EPI_SILU: N = F -> one workgroup per output tile (2 packed tiles)
+    const int gx = (EPI == EPI_SILU) ? ntiles : (ntiles + NT - 1) / NT;
+    const int gy = ((a.M + 15) / 16 + MT - 1) / MT;
+    const size_t lds = (size_t)4 * MT * NT * 4 * 64 * sizeof(float);
+    hipLaunchKernelGGL((gemm_kernel<MT, NT, EPI>), dim3(gx, gy), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    if (a.K % 128 != 0) return hipErrorInvalidValue;
+#define T3_CASE(E, NT)                                                   \
+    switch (mt) {                                                        \
+        case 1: return launch_gemm_t<1, NT, E>(a, s);                    \
+        case 2: return launch_gemm_t<2, NT, E>(a, s);                    \
+        case 4: return launch_gemm_t<4, NT, E>(a, s);                    \
+        default: return launch_gemm_t<8 / NT, NT, E>(a, s);              \
+    }
+    switch (epi) {
+        case EPI_F32: T3_CASE(EPI_F32, 1)
+        case EPI_BF16: T3_CASE(EPI_BF16, 1)
+        case EPI_RESID: T3_CASE(EPI_RESID, 1)
+        case EPI_SILU: T3_CASE(EPI_SILU, 2)
+    }
+#undef T3_CASE
+    return hipErrorInvalidValue;
+}
+
+void pack_weight(const uint16_t* W, int N, int K, int Npad, uint16_t* out) {
+    const int KB = K / 32;
+    for (int nt = 0; nt < Npad / 16; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = nt * 16 + (lane & 15), k0 = kb * 32 + 8 * (lane >> 4);
+                uint16_t* o = out + (((size_t)nt * KB + kb) * 64 + lane) * 8;
+                if (n < N) memcpy(o, W + (size_t)n * K + k0, 16); else memset(o, 0, 16);
+            }
+}
+
+void pack_gate_up(const uint16_t* Wg, const uint16_t* Wu, int Fdim, int K, uint16_t* out) {
+    const int KB = K / 32; const size_t tile = (size_t)KB * 64 * 8;
+    for (int t = 0; t < Fdim / 16; ++t) {
+        pack_weight(Wg + (size_t)t * 16 * K, 16, K, 16, out + (size_t)(2 * t) * tile);
+        pack_weight(Wu + (size_t)t * 16 * K, 16, K, 16, out + (size_t)(2 * t + 1) * tile);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm: one wave per row of 1024.  Contract: lane l owns elements 8l..8l+7 then 512+8l..;
+// sequential x*x adds; butterfly add over xor 32,16,8,4,2,1; rstd = 1/sqrt(ss/1024 + eps);
+// y = bf16(bf16(x*rstd) * w).  gather (optional): input row index per output row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                      uint16_t* __restrict__ y, int rows, const int* __restrict__ gather) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int src = gather ? gather[row] : row;
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)src * D);
+    const uint4 va = xr[lane], vb = xr[64 + lane];
+    float fa[8], fb[8];
+    unpack8(va, fa); unpack8(vb, fb);
+    float ss = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(fa[e], fa[e], ss);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(fb[e], fb[e], ss);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss = ss + __shfl_xor(ss, off);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / 1024.0f) + 1e-5f);
+    const uint4* wr = reinterpret_cast<const uint4*>(w);
+    float wa[8], wb[8];
+    unpack8(wr[lane], wa); unpack8(wr[64 + lane], wb);
+    uint4 oa, ob;
+    oa.x = pack2(rbf(fa[0] * rstd) * wa[0], rbf(fa[1] * rstd) * wa[1]);
+    oa.y = pack2(rbf(fa[2] * rstd) * wa[2], rbf(fa[3] * rstd) * wa[3]);
+    oa.z = pack2(rbf(fa[4] * rstd) * wa[4], rbf(fa[5] * rstd) * wa[5]);
+    oa.w = pack2(rbf(fa[6] * rstd) * wa[6], rbf(fa[7] * rstd) * wa[7]);
+    ob.x = pack2(rbf(fb[0] * rstd) * wb[0], rbf(fb[1] * rstd) * wb[1]);
+    ob.y = pack2(rbf(fb[2] * rstd) * wb[2], rbf(fb[3] * rstd) * wb[3]);
+    ob.z = pack2(rbf(fb[4] * rstd) * wb[4], rbf(fb[5] * rstd) * wb[5]);
+    ob.w = pack2(rbf(fb[6] * rstd) * wb[6], rbf(fb[7] * rstd) * wb[7]);
+    uint4* yr = reinterpret_cast<uint4*>(y + (size_t)row * D);
+    yr[lane] = oa; yr[64 + lane] = ob;
+}
+
+hipError_t launch_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, const int* gather, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, rows, gather);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Embedding rows (t3.py:440-486 decode, 542-561 prefill): one wave per row.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 add_bf8(const uint4& a, const uint4& b) {
+    float fa[8], fb[8]; unpack8(a, fa); unpack8(b, fb);
+    uint4 o;
+    o.x = pack2(fa[0] + fb[0], fa[1] + fb[1]); o.y = pack2(fa[2] + fb[2], fa[3] + fb[3]);
+    o.z = pack2(fa[4] + fb[4], fa[5] + fb[5]); o.w = pack2(fa[6] + fb[6], fa[7] + fb[7]);
+    return o;
+}
+__global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int4 d = a.desc[row];
+    uint4* out = reinterpret_cast<uint4*>(a.h + (size_t)row * D);
+    if (d.x == EMB_ZERO) {
+        out[lane] = make_uint4(0, 0, 0, 0); out[64 + lane] = make_uint4(0, 0, 0, 0);
+    } else if (d.x == EMB_COND) {
+        const float4* src = reinterpret_cast<const float4*>(a.cond + ((size_t)d.y * T3_COND_ROWS + d.z) * D);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const float4 p = src[(half * 64 + lane) * 2], q = src[(half * 64 + lane) * 2 + 1];
+            uint4 o; o.x = pack2(p.x, p.y); o.y = pack2(p.z, p.w); o.z = pack2(q.x, q.y); o.w = pack2(q.z, q.w);
+            out[half * 64 + lane] = o;
+        }
+    } else {
+        const uint16_t* e = (d.x == EMB_TEXT) ? a.text_emb : a.speech_emb;
+        const uint16_t* p = (d.x == EMB_TEXT) ? a.text_pos : a.speech_pos;
+        const uint4* er = reinterpret_cast<const uint4*>(e + (size_t)d.y * D);
+        const uint4* pr = reinterpret_cast<const uint4*>(p + (size_t)d.z * D);
+        out[lane] = add_bf8(er[lane], pr[lane]);
+        out[64 + lane] = add_bf8(er[64 + lane], pr[64 + lane]);
+    }
+}
+hipError_t launch_embed(const EmbedArgs& a, hipStream_t s) {
+    if (a.rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(embed_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE (rotate-half, llama3-scaled table) + paged KV write: one wave per row.
+// lane = 4*head + part; part covers pairs i in [8*part, 8*part+8):  o1 = x1*c - x2*s, o2 = x2*c + x1*s
+// (cos/sin are bf16-valued so both products are exact; one fp32 rounding, then bf16).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rope8(const uint4& x1, const uint4& x2, const float* c, const float* s, uint4& o1, uint4& o2) {
+    float a[8], b[8]; unpack8(x1, a); unpack8(x2, b);
+    float r1[8], r2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { r1[e] = a[e] * c[e] - b[e] * s[e]; r2[e] = b[e] * c[e] + a[e] * s[e]; }
+    o1.x = pack2(r1[0], r1[1]); o1.y = pack2(r1[2], r1[3]); o1.z = pack2(r1[4], r1[5]); o1.w = pack2(r1[6], r1[7]);
+    o2.x = pack2(r2[0], r2[1]); o2.y = pack2(r2[2], r2[3]); o2.z = pack2(r2[4], r2[5]); o2.w = pack2(r2[6], r2[7]);
+}
+__global__ __launch_bounds__(256) void rope_kv_kernel(RopeArgs a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int pos = a.row_pos[row], stream = a.row_stream[row];
+    const int blk = a.block_table[(size_t)stream * a.max_blocks + (pos >> 6)], tok = pos & 63;
+    const int h = lane >> 2, part = lane & 3, i0 = part * 8;
+    float c[8], s[8];
+    {
+        const float4* cp = reinterpret_cast<const float4*>(a.cos_t + (size_t)pos * 32 + i0);
+        const float4* sp = reinterpret_cast<const float4*>(a.sin_t + (size_t)pos * 32 + i0);
+        const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+        c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+        s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
+    }
+    const uint16_t* qr = a.qkv + (size_t)row * QKV;
+    uint4 o1, o2;
+    rope8(*reinterpret_cast<const uint4*>(qr + h * 64 + i0), *reinterpret_cast<const uint4*>(qr + h * 64 + 32 + i0), c, s, o1, o2);
+    uint16_t* qo = a.q_out + (size_t)row * D + h * 64;
+    *reinterpret_cast<uint4*>(qo + i0) = o1; *reinterpret_cast<uint4*>(qo + 32 + i0) = o2;
+    rope8(*reinterpret_cast<const uint4*>(qr + D + h * 64 + i0), *reinterpret_cast<const uint4*>(qr + D + h * 64 + 32 + i0), c, s, o1, o2);
+    uint16_t* kb = a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(0 * H + h) * KV_BLOCK + tok) * HD;
+    *reinterpret_cast<uint4*>(kb + i0) = o1; *reinterpret_cast<uint4*>(kb + 32 + i0) = o2;
+    uint16_t* vb = a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(1 * H + h) * KV_BLOCK + tok) * HD;
+    const uint4* vs = reinterpret_cast<const uint4*>(qr + 2 * D + h * 64 + part * 16);
+    reinterpret_cast<uint4*>(vb + part * 16)[0] = vs[0];
+    reinterpret_cast<uint4*>(vb + part * 16)[1] = vs[1];
+}
+hipError_t launch_rope_kv(const RopeArgs& a, hipStream_t s) {
+    if (a.rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rope_kv_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Paged attention for one (row, head): context = positions 0..row_pos of the row's stream.
+// One workgroup of 4 waves; wave w takes chunks c = w, w+4, ... (chunk = one 64-token KV block of
+// this head = 8 KiB K + 8 KiB V, contiguous, read with fully coalesced 1 KiB wave loads straight to
+// VGPRs).  lane = 8*g + e8: token 8i+g of the chunk (i = 0..7), dims 8*e8..8*e8+7.
+// Per-chunk (m_c, l_c, o_c[64]) go to LDS; wave 0 combines them in ascending chunk order.
+// All orders are the contract's (DESIGN.md "Attention").
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float part[];   // [max_chunks] m | [max_chunks] l | [max_chunks][64] o
+    float* pm = part; float* pl = part + a.max_chunks; float* po = part + 2 * a.max_chunks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = blockIdx.x, row = blockIdx.y;
+    const int stream = a.row_stream[row], L = a.row_pos[row] + 1;
+    const int nc = (L + KV_BLOCK - 1) / KV_BLOCK;
+    const int g = lane >> 3, e8 = lane & 7;
+    float qf[8];
+    unpack8(*reinterpret_cast<const uint4*>(a.q + (size_t)row * D + h * HD + e8 * 8), qf);
+    const int* bt = a.block_table + (size_t)stream * a.max_blocks;
+
+    for (int c = wave; c < nc; c += 4) {
+        const int blk = bt[c];
+        const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + (size_t)(0 * H + h) * KV_BLOCK * HD);
+        const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + (size_t)(1 * H + h) * KV_BLOCK * HD);
+        uint4 kk[8], vv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kk[i] = Kp[i * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vv[i] = Vp[i * 64 + lane];
+        float sc[8];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float kf[8]; unpack8(kk[i], kf);
+            float s = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = __builtin_fmaf(qf[e], kf[e], s);
+            s = s + __shfl_xor(s, 1); s = s + __shfl_xor(s, 2); s = s + __shfl_xor(s, 4);
+            const int t = c * KV_BLOCK + 8 * i + g;
+            sc[i] = (t < L) ? s * 0.125f : -INFINITY;
+            m = fmaxf(m, sc[i]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+        float p[8], lsum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { p[i] = (sc[i] == -INFINITY) ? 0.0f : t3_expf(sc[i] - m); lsum = lsum + p[i]; }
+        lsum = lsum + __shfl_xor(lsum, 8); lsum = lsum + __shfl_xor(lsum, 16); lsum = lsum + __shfl_xor(lsum, 32);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float vf[8]; unpack8(vv[i], vf);
+            const bool valid = (c * KV_BLOCK + 8 * i + g) < L;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(p[i], valid ? vf[e] : 0.0f, o[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = o[e];
+            v = v + __shfl_xor(v, 8); v = v + __shfl_xor(v, 16); v = v + __shfl_xor(v, 32);
+            o[e] = v;
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) po[c * 64 + e8 * 8 + e] = o[e];
+        }
+        if (lane == 0) { pm[c] = m; pl[c] = lsum; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float M = -INFINITY;
+        for (int c = 0; c < nc; ++c) M = fmaxf(M, pm[c]);
+        float l = 0.0f, o = 0.0f;
+        for (int c = 0; c < nc; ++c) {
+            const float w = t3_expf(pm[c] - M);
+            l = __builtin_fmaf(w, pl[c], l);
+            o = __builtin_fmaf(w, po[c * 64 + lane], o);
+        }
+        a.out[(size_t)row * D + h * HD + lane] = (uint16_t)f2bf(o / l);
+    }
+}
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+    if (a.rows <= 0) return hipSuccess;
+    const size_t lds = (size_t)a.max_chunks * 66 * sizeof(float);
+    hipLaunchKernelGGL(attention_kernel, dim3(H, a.rows), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// CFG (t3.py:662, bf16 tensor arithmetic) + sampler.  One workgroup per sampled utterance.
+// Probability mass lives on integer weights w = floor(exp(l - max) * 2^32), so every sum is exact and
+// order-free; thresholds come from binary searches on the weight value (DESIGN.md "Sampler").
+// ------------------------------------------------------------------------------------------------
+constexpr int SPT = 33;                 // elements per thread in contiguous ownership: 256*33 >= 8194
+constexpr int SLOTS = 256 * SPT;
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int off) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, off), hi = __shfl_xor((uint32_t)(v >> 32), off);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* scr) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += shfl_xor_u64(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return scr[0] + scr[1] + scr[2] + scr[3];
+}
+__device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, unsigned long long* scr) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const unsigned long long o = shfl_xor_u64(v, off); v = o > v ? o : v; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long r = scr[0];
+    r = scr[1] > r ? scr[1] : r; r = scr[2] > r ? scr[2] : r; r = scr[3] > r ? scr[3] : r;
+    return r;
+}
+__device__ __forceinline__ float block_max_f32(float v, unsigned long long* scr) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) reinterpret_cast<float*>(scr)[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float* f = reinterpret_cast<const float*>(scr);
+    return fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3]));
+}
+
+__device__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sw[];   // [SLOTS] weights | [8] scratch | [256] partial sums
+    unsigned long long* scr = sw + SLOTS;
+    unsigned long long* psum = scr + 8;
+    const int tid = threadIdx.x, u = blockIdx.x;
+    const int slot = a.sel[u].x;
+    const uint32_t step = (uint32_t)a.sel[u].y;
+    const T3Sampling sp = a.sp[slot];
+    const uint16_t* lc = a.logits + (size_t)(2 * u) * a.ldl;
+    const uint16_t* lu = lc + a.ldl;
+    uint16_t* counts = a.counts + (size_t)slot * VPAD;
+    float* xs = reinterpret_cast<float*>(sw);     // phase A: xs[v] (fp32) lives in the low half of slot v
+
+    // ---- phase A (strided, coalesced): CFG, penalties
+    const bool greedy = sp.temperature < 1e-5f;
+    float mx = -INFINITY;
+    unsigned long long best = 0;
+    for (int v = tid; v < SLOTS; v += 256) {
+        float x = -INFINITY;
+        if (v < V) {
+            const float c = bf2f(lc[v]), un = bf2f(lu[v]);
+            const float d = rbf(c - un);
+            const float e = rbf(a.cfg * d);
+            x = rbf(c + e);
+            if (a.dbg) a.dbg[(size_t)slot * V + v] = x;
+            const uint32_t cnt = counts[v];
+            if (cnt > 0) {
+                if (sp.repetition_penalty != 1.0f) x = (x > 0.0f) ? x / sp.repetition_penalty : x * sp.repetition_penalty;
+                x = x - sp.frequency_penalty * (float)cnt;
+                x = x - sp.presence_penalty;
+            }
+            if (greedy) {
+                const float xz = x + 0.0f;                       // -0 -> +0 so that the key order equals '>' on floats
+                uint32_t b = __float_as_uint(xz);
+                b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+                const unsigned long long key = ((unsigned long long)b << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)v);
+                best = key > best ? key : best;
+            } else {
+                x = x / sp.temperature;
+                mx = fmaxf(mx, x);
+            }
+        }
+        xs[2 * v] = x;
+    }
+    int token;
+    if (greedy) {
+        best = block_max_u64(best, scr);
+        token = (int)(0xFFFFFFFFu - (uint32_t)best);
+    } else {
+        mx = block_max_f32(mx, scr);
+        // ---- weights (same strided ownership as phase A, so no barrier needed before overwriting)
+        for (int v = tid; v < SLOTS; v += 256) {
+            const float x = xs[2 * v];
+            unsigned long long w = 0;
+            if (v < V) w = (unsigned long long)(t3_expf(x - mx) * 4294967296.0f);
+            sw[v] = w;
+        }
+        __syncthreads();
+        const int v0 = tid * SPT;
+        unsigned long long wmax = 0;
+        for (int i = 0; i < SPT; ++i) { const unsigned long long w = sw[v0 + i]; wmax = w > wmax ? w : wmax; }
+        wmax = block_max_u64(wmax, scr);
+        if (sp.min_p > 0.0f) {
+            const double thr = (double)sp.min_p * (double)wmax;
+            for (int i = 0; i < SPT; ++i) if ((double)sw[v0 + i] < thr) sw[v0 + i] = 0;
+        }
+        if (sp.top_k > 0 && sp.top_k < V) {
+            unsigned long long lo = 0, hi = wmax;
+            while (lo < hi) {
+                const unsigned long long mid = lo + (hi - lo + 1) / 2;
+                unsigned long long cnt = 0;
+                for (int i = 0; i < SPT; ++i) cnt += (sw[v0 + i] >= mid) ? 1 : 0;
+                cnt = block_sum_u64(cnt, scr);
+                if (cnt >= (unsigned long long)sp.top_k) lo = mid; else hi = mid - 1;
+            }
+            for (int i = 0; i < SPT; ++i) if (sw[v0 + i] < lo) sw[v0 + i] = 0;
+        }
+        if (sp.top_p < 1.0f) {
+            unsigned long long W = 0;
+            for (int i = 0; i < SPT; ++i) W += sw[v0 + i];
+            W = block_sum_u64(W, scr);
+            const unsigned long long Tm = (unsigned long long)((1.0 - (double)sp.top_p) * (double)W);
+            unsigned long long lo = 0, hi = wmax;
+            while (lo < hi) {
+                const unsigned long long mid = lo + (hi - lo + 1) / 2;
+                unsigned long long s = 0;
+                for (int i = 0; i < SPT; ++i) { const unsigned long long w = sw[v0 + i]; s += (w < mid) ? w : 0; }
+                s = block_sum_u64(s, scr);
+                if (s <= Tm) lo = mid; else hi = mid - 1;
+            }
+            if (lo > 0) {
+                unsigned long long below = 0, ties = 0;
+                for (int i = 0; i < SPT; ++i) { const unsigned long long w = sw[v0 + i]; below += (w < lo) ? w : 0; ties += (w == lo) ? 1 : 0; }
+                const unsigned long long my_ties = ties;
+                below = block_sum_u64(below, scr);
+                ties = block_sum_u64(ties, scr);
+                unsigned long long r = (Tm - below) / lo;
+                if (lo == wmax && r > ties - 1) r = ties - 1;
+                if (r > ties) r = ties;
+                // ties are dropped highest index first
+                __syncthreads();
+                psum[tid] = my_ties;
+                __syncthreads();
+                unsigned long long above = 0;
+                if (r > 0) for (int t = tid + 1; t < 256; ++t) above += psum[t];
+                for (int i = SPT - 1; i >= 0; --i) {
+                    const unsigned long long w = sw[v0 + i];
+                    if (w < lo) sw[v0 + i] = 0;
+                    else if (w == lo) { if (above < r) sw[v0 + i] = 0; ++above; }
+                }
+            }
+        }
+        // ---- draw
+        unsigned long long mine = 0;
+        for (int i = 0; i < SPT; ++i) mine += sw[v0 + i];
+        __syncthreads();
+        psum[tid] = mine;
+        __syncthreads();
+        unsigned long long excl = 0, Wk = 0;
+        for (int t = 0; t < 256; ++t) { const unsigned long long p = psum[t]; if (t < tid) excl += p; Wk += p; }
+        uint32_t rnd[4];
+        philox4x32_10(step, (uint32_t)sp.uid, (uint32_t)(sp.uid >> 32), 0u, (uint32_t)sp.seed, (uint32_t)(sp.seed >> 32), rnd);
+        const unsigned long long uu = ((unsigned long long)rnd[1] << 32) | rnd[0];
+        const unsigned long long target = __umul64hi(uu, Wk);
+        int* tokp = reinterpret_cast<int*>(scr + 4);
+        if (mine > 0 && target >= excl && target < excl + mine) {
+            unsigned long long cum = excl; int found = v0;
+            for (int i = 0; i < SPT; ++i) { const unsigned long long w = sw[v0 + i]; if (w > 0) { cum += w; found = v0 + i; if (cum > target) break; } }
+            *tokp = found;
+        }
+        __syncthreads();
+        token = *tokp;
+    }
+    if (tid == 0) {
+        a.out_tok[u] = token;
+        const uint16_t cnt = counts[token];
+        if (cnt < 65535) counts[token] = cnt + 1;
+    }
+}
+hipError_t launch_sampler(const SampleArgs& a, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    const size_t lds = (size_t)(SLOTS + 8 + 256) * sizeof(unsigned long long);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sampler_kernel, dim3(a.n), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+__global__ void expf_kernel(const float* x, float* y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = t3_expf(x[i]);
+}
+hipError_t launch_expf(const float* x, float* y, int n, hipStream_t s) {
+    hipLaunchKernelGGL(expf_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);
+    return hipGetLastError();
+}
+
+// llama3-scaled RoPE table (t3-model/config.json:21-28): inv_freq fp32-valued, angle and cos/sin in
+// double, rounded to fp32 then bf16 (the cache is held in the model dtype, as vLLM and HF do).
+void rope_tables(int max_pos, float* cos_t, float* sin_t) {
+    double inv[32];
+    const double theta = 500000.0, factor = 8.0, lo = 1.0, hi = 4.0, old = 8192.0, pi = 3.14159265358979323846;
+    for (int i = 0; i < 32; ++i) {
+        double f = pow(theta, -(2.0 * i) / 64.0);
+        const double wl = 2.0 * pi / f;
+        if (wl > old / lo) f = f / factor;
+        else if (wl >= old / hi) { const double sm = (old / wl - lo) / (hi - lo); f = (1.0 - sm) * f / factor + sm * f; }
+        inv[i] = (double)(float)f;
+    }
+    auto rb = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); u &= 0xffff0000u; float r; memcpy(&r, &u, 4); return r; };
+    for (int p = 0; p < max_pos; ++p)
+        for (int i = 0; i < 32; ++i) {
+            const double ang = (double)p * inv[i];
+            cos_t[(size_t)p * 32 + i] = rb((float)cos(ang));
+            sin_t[(size_t)p * 32 + i] = rb((float)sin(ang));
+        }
+}
+
+}  // namespace t3

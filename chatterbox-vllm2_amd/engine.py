@@ -1,0 +1,306 @@
+"""ctypes binding of libt3engine.so (include/t3_engine.h).
+
+The HIP extension is the only compute path: if the shared library is missing or no GPU is visible,
+construction raises -- there is no CPU or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+import subprocess
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import constants as C
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libt3engine.so")
+
+T3_OK, T3_E_INVALID, T3_E_DEVICE, T3_E_NOMEM, T3_E_STATE, T3_E_NOTFOUND = 0, -1, -2, -3, -4, -5
+
+
+class T3EngineConfig(ct.Structure):
+    _fields_ = [
+        ("device_id", ct.c_int32), ("n_layers", ct.c_int32), ("text_vocab", ct.c_int32),
+        ("max_model_len", ct.c_int32), ("max_seqs", ct.c_int32), ("max_batched_rows", ct.c_int32),
+        ("kv_bytes", ct.c_int64), ("gpu_memory_utilization", ct.c_float), ("cfg_scale", ct.c_float),
+        ("enforce_eager", ct.c_int32), ("debug_logits", ct.c_int32),
+    ]
+
+
+class T3Sampling(ct.Structure):
+    _fields_ = [
+        ("temperature", ct.c_float), ("top_p", ct.c_float), ("min_p", ct.c_float),
+        ("repetition_penalty", ct.c_float), ("presence_penalty", ct.c_float), ("frequency_penalty", ct.c_float),
+        ("top_k", ct.c_int32), ("max_tokens", ct.c_int32), ("ignore_eos", ct.c_int32), ("stop_token", ct.c_int32),
+        ("seed", ct.c_uint64), ("uid", ct.c_uint64), ("pos_policy", ct.c_int32), ("_pad", ct.c_int32),
+    ]
+
+
+class T3StepResult(ct.Structure):
+    _fields_ = [
+        ("n_rows", ct.c_int32), ("n_prefill_rows", ct.c_int32), ("n_sampled", ct.c_int32), ("n_finished", ct.c_int32),
+        ("n_running", ct.c_int32), ("n_waiting", ct.c_int32), ("finished_ids", ct.c_int64 * 64),
+    ]
+
+
+class T3Stats(ct.Structure):
+    _fields_ = [
+        ("steps", ct.c_int64), ("decode_steps", ct.c_int64), ("tokens_generated", ct.c_int64),
+        ("prefill_rows", ct.c_int64), ("decode_rows", ct.c_int64),
+        ("gpu_ms_total", ct.c_double), ("gpu_ms_decode", ct.c_double), ("algo_bytes_decode", ct.c_double),
+        ("sum_ctx_decode", ct.c_double),
+        ("kv_blocks_total", ct.c_int64), ("kv_blocks_free", ct.c_int64), ("weight_bytes", ct.c_int64),
+    ]
+
+
+# every symbol include/t3_engine.h declares (tests/test_abi.py checks the library exports all of them)
+ABI_SYMBOLS = [
+    "t3_create", "t3_destroy", "t3_last_error", "t3_load_tensor", "t3_finalize_weights", "t3_add_request",
+    "t3_step", "t3_run_until_done", "t3_num_unfinished", "t3_get_output", "t3_release_request",
+    "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_kernel_ms",
+    "t3k_gemm", "t3k_rmsnorm", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_sample", "t3k_expf",
+]
+
+KERNEL_CLASSES = ["gemm_qkv", "gemm_o", "gemm_gateup", "gemm_down", "gemm_head", "attention", "rmsnorm",
+                  "rope_kv", "embed", "sampler"]
+
+
+def build_library(force: bool = False) -> str:
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-s", "-j4"] + (["-B"] if force else [])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C chatterbox-vllm2_amd/csrc).  The T3 engine has no fallback path.")
+    L = ct.CDLL(LIB_PATH)
+    vp, i32, i64 = ct.c_void_p, ct.c_int32, ct.c_int64
+    L.t3_create.argtypes = [ct.POINTER(T3EngineConfig), ct.POINTER(vp)]
+    L.t3_destroy.argtypes = [vp]
+    L.t3_last_error.argtypes = [vp]; L.t3_last_error.restype = ct.c_char_p
+    L.t3_load_tensor.argtypes = [vp, ct.c_char_p, vp, i32, i32]
+    L.t3_finalize_weights.argtypes = [vp]
+    L.t3_add_request.argtypes = [vp, i64, vp, i32, vp, ct.POINTER(T3Sampling)]
+    L.t3_step.argtypes = [vp, ct.POINTER(T3StepResult)]
+    L.t3_run_until_done.argtypes = [vp]
+    L.t3_num_unfinished.argtypes = [vp]
+    L.t3_get_output.argtypes = [vp, i64, vp, ct.POINTER(i32), ct.POINTER(i32)]
+    L.t3_release_request.argtypes = [vp, i64]
+    L.t3_debug_logits.argtypes = [vp, i64, vp]
+    L.t3_stats.argtypes = [vp, ct.POINTER(T3Stats)]
+    L.t3_reset_stats.argtypes = [vp]
+    L.t3_set_profile.argtypes = [vp, i32]
+    L.t3_kernel_ms.argtypes = [vp, ct.c_char_p, ct.POINTER(ct.c_double), ct.POINTER(i64)]
+    L.t3k_gemm.argtypes = [vp, vp, i32, i32, i32, vp, i32]
+    L.t3k_rmsnorm.argtypes = [vp, vp, vp, i32]
+    L.t3k_silu_mul_gemm.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.t3k_rope_attention.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.t3k_sample.argtypes = [vp, i32, vp, ct.POINTER(T3Sampling), ct.c_float, ct.c_uint32, vp, vp]
+    L.t3k_expf.argtypes = [vp, vp, i32]
+    for s in ABI_SYMBOLS:
+        if s != "t3_last_error":
+            getattr(L, s).restype = ct.c_int
+    _lib = L
+    return L
+
+
+class T3Error(RuntimeError):
+    pass
+
+
+def _raise(code: int, msg: str):
+    # ValueError surfaces as HTTP 400 in the reference server (api_server.py:323-326)
+    if code == T3_E_INVALID:
+        raise ValueError(msg)
+    if code == T3_E_NOMEM:
+        raise MemoryError(msg)
+    raise T3Error(f"[{code}] {msg}")
+
+
+def make_sampling(temperature=0.8, top_p=1.0, min_p=0.0, repetition_penalty=2.0, presence_penalty=0.0,
+                  frequency_penalty=0.0, top_k=0, max_tokens=1000, ignore_eos=False,
+                  stop_token=C.STOP_SPEECH_TOKEN, seed=0, uid=0, pos_policy=0) -> T3Sampling:
+    return T3Sampling(float(temperature), float(top_p), float(min_p), float(repetition_penalty),
+                      float(presence_penalty), float(frequency_penalty), int(top_k), int(max_tokens),
+                      int(bool(ignore_eos)), int(stop_token), int(seed), int(uid), int(pos_policy), 0)
+
+
+class T3Engine:
+    """Thin object wrapper over one engine handle (one GPU)."""
+
+    def __init__(self, n_layers: int = C.N_LAYERS, text_vocab: int = C.TEXT_VOCAB_EN, max_model_len: int = 1000,
+                 max_seqs: int = 32, device_id: int = 0, kv_bytes: int = 0, gpu_memory_utilization: float = 0.9,
+                 cfg_scale: Optional[float] = None, enforce_eager: bool = True, debug_logits: bool = False,
+                 max_batched_rows: int = 0):
+        self.lib = load_library()
+        if cfg_scale is None:
+            cfg_scale = float(os.environ.get("CHATTERBOX_CFG_SCALE", "0.5"))   # t3.py:296
+        self.cfg = T3EngineConfig(device_id, n_layers, text_vocab, max_model_len, max_seqs, max_batched_rows,
+                                  int(kv_bytes), float(gpu_memory_utilization), float(cfg_scale),
+                                  int(enforce_eager), int(debug_logits))
+        self.h = ct.c_void_p()
+        rc = self.lib.t3_create(ct.byref(self.cfg), ct.byref(self.h))
+        if rc:
+            _raise(rc, self.lib.t3_last_error(None).decode())
+
+    def _chk(self, rc: int):
+        if rc:
+            _raise(rc, self.lib.t3_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.t3_destroy(self.h)
+            self.h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights
+    def load_tensors(self, tensors: Iterable[Tuple[str, torch.Tensor]], strict: bool = False) -> List[str]:
+        """Feed (checkpoint name, tensor) pairs; unknown names are skipped like t3.py:316-319."""
+        skipped = []
+        for name, t in tensors:
+            t = t.to(torch.bfloat16).contiguous()
+            rows, cols = (t.shape[0], t.shape[1]) if t.dim() == 2 else (1, t.numel())
+            rc = self.lib.t3_load_tensor(self.h, name.encode(), ct.c_void_p(t.data_ptr()), rows, cols)
+            if rc == T3_E_NOTFOUND and not strict:
+                skipped.append(name)
+                continue
+            self._chk(rc)
+        return skipped
+
+    def finalize(self):
+        self._chk(self.lib.t3_finalize_weights(self.h))
+
+    # ---- requests
+    def add_request(self, req_id: int, prompt_ids: Sequence[int], cond_emb: torch.Tensor, sp: T3Sampling):
+        ids = np.ascontiguousarray(np.asarray(prompt_ids, dtype=np.int32))
+        cond = cond_emb.detach().to("cpu", torch.float32).contiguous()
+        if tuple(cond.shape) != (C.CONDITIONING_SIZE, C.HIDDEN):
+            raise ValueError(f"conditionals must be [{C.CONDITIONING_SIZE}, {C.HIDDEN}], got {tuple(cond.shape)}")
+        self._chk(self.lib.t3_add_request(self.h, int(req_id), ct.c_void_p(ids.ctypes.data), len(ids),
+                                          ct.c_void_p(cond.data_ptr()), ct.byref(sp)))
+
+    def step(self) -> T3StepResult:
+        r = T3StepResult()
+        self._chk(self.lib.t3_step(self.h, ct.byref(r)))
+        return r
+
+    def run_until_done(self):
+        self._chk(self.lib.t3_run_until_done(self.h))
+
+    def num_unfinished(self) -> int:
+        return int(self.lib.t3_num_unfinished(self.h))
+
+    def get_output(self, req_id: int) -> Tuple[List[int], int]:
+        """(offset-space token ids >= 2500, finish_reason)"""
+        cap = int(self.cfg.max_model_len)
+        buf = np.zeros(cap, dtype=np.int32)
+        n = ct.c_int32(cap); fr = ct.c_int32(0)
+        self._chk(self.lib.t3_get_output(self.h, int(req_id), ct.c_void_p(buf.ctypes.data), ct.byref(n), ct.byref(fr)))
+        return buf[: n.value].tolist(), int(fr.value)
+
+    def release(self, req_id: int):
+        self._chk(self.lib.t3_release_request(self.h, int(req_id)))
+
+    def debug_logits(self, req_id: int) -> torch.Tensor:
+        out = torch.empty(C.SPEECH_VOCAB, dtype=torch.float32)
+        self._chk(self.lib.t3_debug_logits(self.h, int(req_id), ct.c_void_p(out.data_ptr())))
+        return out
+
+    # ---- measurement
+    def stats(self) -> T3Stats:
+        s = T3Stats()
+        self._chk(self.lib.t3_stats(self.h, ct.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._chk(self.lib.t3_reset_stats(self.h))
+
+    def set_profile(self, on: bool):
+        self._chk(self.lib.t3_set_profile(self.h, int(on)))
+
+    def kernel_ms(self, name: str) -> Tuple[float, int]:
+        ms = ct.c_double(0); n = ct.c_int64(0)
+        self._chk(self.lib.t3_kernel_ms(self.h, name.encode(), ct.byref(ms), ct.byref(n)))
+        return float(ms.value), int(n.value)
+
+
+# ---------------------------------------------------------------- kernel-level entry points (parity tests)
+def _chk_k(rc: int, what: str):
+    if rc == T3_E_DEVICE:
+        raise T3Error(f"{what}: no usable HIP device / HIP error (the kernels have no CPU fallback)")
+    if rc:
+        raise ValueError(f"{what}: invalid argument ({rc})")
+
+
+def _bf(t: torch.Tensor) -> torch.Tensor:
+    assert t.dtype == torch.bfloat16 and t.device.type == "cpu"
+    return t.contiguous()
+
+
+def k_gemm(x: torch.Tensor, W: torch.Tensor, mt: int = 0) -> torch.Tensor:
+    x, W = _bf(x), _bf(W)
+    M, K = x.shape; N = W.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32)
+    _chk_k(load_library().t3k_gemm(x.data_ptr(), W.data_ptr(), M, K, N, out.data_ptr(), mt), "t3k_gemm")
+    return out
+
+
+def k_rmsnorm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    x, w = _bf(x), _bf(w)
+    y = torch.empty_like(x)
+    _chk_k(load_library().t3k_rmsnorm(x.data_ptr(), w.data_ptr(), y.data_ptr(), x.shape[0]), "t3k_rmsnorm")
+    return y
+
+
+def k_silu_mul_gemm(x: torch.Tensor, Wg: torch.Tensor, Wu: torch.Tensor) -> torch.Tensor:
+    x, Wg, Wu = _bf(x), _bf(Wg), _bf(Wu)
+    M, Fd = x.shape[0], Wg.shape[0]
+    out = torch.empty(M, Fd, dtype=torch.bfloat16)
+    _chk_k(load_library().t3k_silu_mul_gemm(x.data_ptr(), Wg.data_ptr(), Wu.data_ptr(), M, Fd, out.data_ptr()), "t3k_silu_mul_gemm")
+    return out
+
+
+def k_rope_attention(qkv: torch.Tensor, row_stream, row_pos, n_streams: int, max_pos: int) -> torch.Tensor:
+    qkv = _bf(qkv)
+    rs = np.ascontiguousarray(np.asarray(row_stream, dtype=np.int32)); rp = np.ascontiguousarray(np.asarray(row_pos, dtype=np.int32))
+    out = torch.empty(qkv.shape[0], C.HIDDEN, dtype=torch.bfloat16)
+    _chk_k(load_library().t3k_rope_attention(qkv.data_ptr(), rs.ctypes.data, rp.ctypes.data, qkv.shape[0], n_streams, max_pos,
+                                             out.data_ptr()), "t3k_rope_attention")
+    return out
+
+
+def k_sample(logits2: torch.Tensor, counts: torch.Tensor, sp: T3Sampling, cfg: float, step: int):
+    """logits2 [2, ld] bf16 (cond, uncond); counts uint16 [8194] (updated in place). -> (token, post-CFG logits)"""
+    logits2 = _bf(logits2)
+    assert counts.dtype == torch.uint16 and counts.numel() == C.SPEECH_VOCAB
+    tok = ct.c_int32(0)
+    lg = torch.empty(C.SPEECH_VOCAB, dtype=torch.float32)
+    _chk_k(load_library().t3k_sample(logits2.data_ptr(), logits2.shape[1], counts.data_ptr(), ct.byref(sp), ct.c_float(cfg),
+                                     ct.c_uint32(step), ct.byref(tok), lg.data_ptr()), "t3k_sample")
+    return int(tok.value), lg
+
+
+def k_expf(x: torch.Tensor) -> torch.Tensor:
+    x = x.to(torch.float32).contiguous()
+    y = torch.empty_like(x)
+    _chk_k(load_library().t3k_expf(x.data_ptr(), y.data_ptr(), x.numel()), "t3k_expf")
+    return y

@@ -1,0 +1,159 @@
+/*
+ * t3_engine.h -- C ABI of the MI355X-native T3 speech-token decode engine (libt3engine.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of groxaxo/chatterbox-vllm2: everything that
+ * happens between `LLM.generate(prompts, sampling_params)` and `output.token_ids`
+ * (reference src/chatterbox_vllm/tts.py:445-465, 485) -- i.e. what the reference delegates to
+ * vllm==0.10.0 plus its model plugin src/chatterbox_vllm/models/t3/t3.py.  The reference is pure
+ * Python, so the "FFI" a maintainer binds is ctypes (see INTEGRATION.md for the stub).
+ *
+ * Conventions: every function returns 0 on success or a negative T3_E_* code; the message is
+ * available from t3_last_error().  No exceptions cross the boundary.  The caller owns all host
+ * buffers; the engine owns all device memory.  One handle per GPU; a handle is NOT thread-safe
+ * (one driver thread per handle -- the reference's caller is a single blocking FastAPI handler,
+ * api_server.py:265-271).  Token ids at this boundary are in the reference's OFFSET space
+ * (speech id + 2500, t3.py:49,669-672) unless a function says "speech-space".
+ */
+#ifndef T3_ENGINE_H
+#define T3_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T3_OK 0
+#define T3_E_INVALID (-1)   /* bad argument (maps to ValueError -> HTTP 400, api_server.py:323-326) */
+#define T3_E_DEVICE (-2)    /* HIP error */
+#define T3_E_NOMEM (-3)     /* KV pool / device memory exhausted */
+#define T3_E_STATE (-4)     /* call not valid in this state (e.g. step before finalize_weights) */
+#define T3_E_NOTFOUND (-5)  /* unknown request id / tensor name */
+
+#define T3_SPEECH_TOKEN_OFFSET 2500 /* t3.py:49 */
+#define T3_COND_ROWS 34             /* t3.py:42 */
+#define T3_HIDDEN 1024
+#define T3_SPEECH_VOCAB 8194        /* t3_config.py:10 */
+
+typedef struct T3Engine* T3Handle;
+
+/* Replaces the kwargs of `LLM(model=..., gpu_memory_utilization=, enforce_eager=, max_model_len=, **kw)`
+ * (tts.py:150-171) and the env var CHATTERBOX_CFG_SCALE (t3.py:296). */
+typedef struct {
+    int32_t device_id;
+    int32_t n_layers;          /* 30 for the real model (config.json:17); small values for tests */
+    int32_t text_vocab;        /* 704 English / 2454 multilingual (t3.py:270) */
+    int32_t max_model_len;     /* tts.py:164 */
+    int32_t max_seqs;          /* utterance slots (vLLM max_num_seqs); each slot = 2 CFG streams */
+    int32_t max_batched_rows;  /* rows (stream-tokens) per step budget, >= 2*max_seqs; 0 = default */
+    int64_t kv_bytes;          /* KV pool size; 0 = derive from gpu_memory_utilization */
+    float gpu_memory_utilization; /* fraction of total HBM the engine may use (tts.py:162) */
+    float cfg_scale;           /* CHATTERBOX_CFG_SCALE, default 0.5 (t3.py:296) */
+    int32_t enforce_eager;     /* 1: never use hipGraph replay (tts.py:163) */
+    int32_t debug_logits;      /* 1: keep post-CFG logits of each sampled step for t3_debug_logits */
+} T3EngineConfig;
+
+/* Replaces vllm.SamplingParams as configured at tts.py:455-464 (+ the kwargs it forwards). */
+typedef struct {
+    float temperature;         /* < 1e-5 => greedy */
+    float top_p;               /* 1.0 = off */
+    float min_p;               /* 0.0 = off (reference accepts min_p but never forwards it, tts.py:415) */
+    float repetition_penalty;  /* 1.0 = off; reference default 2.0 (tts.py:416) */
+    float presence_penalty;
+    float frequency_penalty;
+    int32_t top_k;             /* <= 0 = off */
+    int32_t max_tokens;        /* tts.py:459 */
+    int32_t ignore_eos;        /* fixed-length generation for synthetic benchmarks */
+    int32_t stop_token;        /* SPEECH-SPACE stop id, 6562 (= 9062 - 2500, tts.py:458); -1 none */
+    uint64_t seed;
+    uint64_t uid;              /* utterance id keying the RNG stream: results do not depend on batch
+                                  composition or on data-parallel sharding */
+    int32_t pos_policy;        /* 0: k-th generated token uses speech_pos_emb[k] (SURVEY.md 9 Q1 "exact");
+                                  1: index 0 for every decode token (the literal fallback of t3.py:464) */
+    int32_t _pad;
+} T3Sampling;
+
+typedef struct {
+    int32_t n_rows;            /* rows processed this step */
+    int32_t n_prefill_rows;
+    int32_t n_sampled;         /* utterances that produced a token this step */
+    int32_t n_finished;        /* finished this step */
+    int32_t n_running;         /* after the step */
+    int32_t n_waiting;
+    int64_t finished_ids[64];  /* first min(n_finished, 64) */
+} T3StepResult;
+
+typedef struct {
+    int64_t steps;
+    int64_t decode_steps;          /* steps with no prefill rows */
+    int64_t tokens_generated;
+    int64_t prefill_rows;
+    int64_t decode_rows;
+    double gpu_ms_total;           /* HIP-event time of all steps */
+    double gpu_ms_decode;          /* ... of decode-only steps */
+    double algo_bytes_decode;      /* SURVEY.md 8(d) formula summed over decode-only steps */
+    double sum_ctx_decode;         /* sum over decode rows of context length */
+    int64_t kv_blocks_total, kv_blocks_free;
+    int64_t weight_bytes;
+} T3Stats;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int t3_create(const T3EngineConfig* cfg, T3Handle* out);
+int t3_destroy(T3Handle h);                      /* `del self.t3`, tts.py:527-529 */
+const char* t3_last_error(T3Handle h);           /* h may be NULL for create() failures */
+
+/* ---- weights: T3VllmModel.load_weights (t3.py:300-332) ---------------------------------
+ * name: checkpoint tensor name ("tfmr.layers.3.self_attn.q_proj.weight", "speech_emb.weight",
+ * "text_pos_emb.emb.weight", "speech_head.weight", ...).  Unknown prefixes (cond_enc.*, text_head.*)
+ * return T3_E_NOTFOUND and may be ignored by the caller, as t3.py:316-319 does.
+ * data: host or device pointer to bf16 ([rows][cols], row-major).                          */
+int t3_load_tensor(T3Handle h, const char* name, const void* data_bf16, int32_t rows, int32_t cols);
+int t3_finalize_weights(T3Handle h);             /* packs weights for the GEMM kernels, builds RoPE tables, allocates the KV pool */
+
+/* ---- requests: LLM.generate (tts.py:445-465) -------------------------------------------
+ * prompt_ids: the FINAL prompt [695, x*32, 696, text ids..., 697] of length T (t3.py:189-200);
+ * cond_emb: fp32 [34][1024] host buffer (tts.py:286 hands the conditionals over on CPU).   */
+int t3_add_request(T3Handle h, int64_t req_id, const int32_t* prompt_ids, int32_t T,
+                   const float* cond_emb, const T3Sampling* sampling);
+int t3_step(T3Handle h, T3StepResult* res);      /* admit -> prefill/decode rows -> sample, once */
+int t3_run_until_done(T3Handle h);               /* C++ loop, no Python per step */
+int t3_num_unfinished(T3Handle h);
+/* ids: offset-space token ids (>= 2500), the stop id included when hit.
+ * On entry *n = capacity; on exit *n = number of tokens.  finish_reason: 0 running, 1 stop, 2 length. */
+int t3_get_output(T3Handle h, int64_t req_id, int32_t* ids, int32_t* n, int32_t* finish_reason);
+int t3_release_request(T3Handle h, int64_t req_id);   /* forget a finished request */
+
+/* ---- parity / measurement hooks --------------------------------------------------------- */
+/* post-CFG logits [8194] (speech-space, before the 2500-wide -inf pad of t3.py:669-672) of the
+ * most recent sampled step of req_id; needs cfg.debug_logits = 1. */
+int t3_debug_logits(T3Handle h, int64_t req_id, float* out_8194);
+int t3_stats(T3Handle h, T3Stats* out);
+int t3_reset_stats(T3Handle h);
+/* Average duration (ms) per launch of each kernel class over decode-only steps since the last reset,
+ * measured with HIP events on the engine's stream when profiling is on (t3_set_profile).
+ * names: "gemm_qkv","gemm_o","gemm_gateup","gemm_down","gemm_head","attention","rmsnorm","rope_kv","embed","sampler". */
+int t3_set_profile(T3Handle h, int32_t on);
+int t3_kernel_ms(T3Handle h, const char* name, double* avg_ms, int64_t* launches);
+
+/* ---- kernel-level entry points (host buffers in, host buffers out; used by the parity tests) ----
+ * Each runs exactly the kernel the engine uses, on the current device, and waits for it.      */
+int t3k_gemm(const void* x_bf16 /*[M][K]*/, const void* w_bf16 /*[N][K]*/, int32_t M, int32_t K, int32_t N,
+             float* out_f32 /*[M][N]*/, int32_t mt /*0 = auto*/);
+int t3k_rmsnorm(const void* x_bf16, const void* w_bf16, void* y_bf16, int32_t rows);
+int t3k_silu_mul_gemm(const void* x_bf16 /*[M][1024]*/, const void* wg_bf16 /*[F][1024]*/, const void* wu_bf16,
+                      int32_t M, int32_t F, void* out_bf16 /*[M][F]*/);
+/* RoPE + paged-KV write + paged attention for `rows` rows of ONE layer over a scratch pool:
+ * qkv [rows][3072] bf16 (pre-RoPE), row_stream/row_pos int32 [rows]; rows are processed in the given
+ * order in ONE launch sequence (all KV writes, then all attention), so rows of the same stream must
+ * cover a prefix of positions.  out [rows][1024] bf16.                                        */
+int t3k_rope_attention(const void* qkv_bf16, const int32_t* row_stream, const int32_t* row_pos, int32_t rows,
+                       int32_t n_streams, int32_t max_pos, void* out_bf16);
+/* CFG + sampler: logits bf16 [2][ldl] (cond row, uncond row), counts uint16 [8194] (updated). */
+int t3k_sample(const void* logits2_bf16, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg,
+               uint32_t step, int32_t* token_out, float* logits_out_8194 /*nullable*/);
+int t3k_expf(const float* x, float* y, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T3_ENGINE_H */

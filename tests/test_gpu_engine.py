@@ -1,0 +1,141 @@
+"""Engine-level parity through the C ABI: token ids BIT-EXACT against the oracle, post-CFG logits
+bit-identical at every step (stated tolerance: 0 ulp; the contract fixes all rounding), plus the
+scheduler properties the domain offers (batch invariance, continuous batching, chunked prefill)."""
+import numpy as np
+import pytest
+import torch
+
+from util import assert_bit_equal, make_prompt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    from chatterbox_vllm2_amd import engine
+    engine.load_library()
+    return engine
+
+
+@pytest.fixture(scope="module")
+def cond():
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb
+    return synthetic_cond_emb(1)
+
+
+@pytest.fixture(scope="module")
+def tiny_engine(E, tiny_weights):
+    eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=400, max_seqs=8, kv_bytes=1 << 30, debug_logits=True)
+    eng.load_tensors(tiny_weights); eng.finalize()
+    yield eng
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def tiny_oracle(oracle, tiny_weights):
+    m = oracle.OracleModel(2, 704, max_pos=400, n_streams=2).load(tiny_weights)
+    yield m
+    m.close()
+
+
+CASES = [dict(temperature=0.0), dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=5),
+         dict(temperature=0.8, top_p=1.0, repetition_penalty=2.0, seed=6, pos_policy=1)]
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_single_utterance_ids_and_logits(E, oracle, tiny_engine, tiny_oracle, cond, kw):
+    prompt = make_prompt(20, seed=1)
+    n = 40
+    want, want_lg = tiny_oracle.generate(prompt, cond, oracle.make_sampling(max_tokens=n, ignore_eos=True, uid=3, **kw), want_logits=True, max_model_len=400)
+    tiny_engine.add_request(100, prompt, cond, E.make_sampling(max_tokens=n, ignore_eos=True, uid=3, **kw))
+    step = 0
+    while tiny_engine.num_unfinished():
+        r = tiny_engine.step()
+        if r.n_sampled and tiny_engine.num_unfinished():
+            assert_bit_equal(tiny_engine.debug_logits(100), want_lg[step], f"logits step {step}")
+        step += r.n_sampled
+    got, fr = tiny_engine.get_output(100)
+    tiny_engine.release(100)
+    assert fr == 2
+    assert [t - 2500 for t in got] == want
+
+
+def test_stop_token_and_limits(E, oracle, tiny_engine, tiny_oracle, cond):
+    prompt = make_prompt(12, seed=2)
+    ref, _ = tiny_oracle.generate(prompt, cond, oracle.make_sampling(temperature=0.0, max_tokens=30, ignore_eos=True), max_model_len=400)
+    stop = ref[7]                     # pretend the 8th greedy token is the stop id
+    first = ref.index(stop)
+    want, _ = tiny_oracle.generate(prompt, cond, oracle.make_sampling(temperature=0.0, max_tokens=30, stop_token=stop), max_model_len=400)
+    assert want == ref[: first + 1]
+    tiny_engine.add_request(1, prompt, cond, E.make_sampling(temperature=0.0, max_tokens=30, stop_token=stop))
+    tiny_engine.run_until_done()
+    got, fr = tiny_engine.get_output(1); tiny_engine.release(1)
+    assert fr == 1 and [t - 2500 for t in got] == want          # the stop id is emitted
+
+
+def test_batch_invariance_and_continuous_batching(E, oracle, tiny_engine, tiny_oracle, cond):
+    """12 utterances of different prompt lengths and lengths through 8 slots: admit/retire between steps;
+    every stream must equal its single-utterance oracle stream (independence of batch composition)."""
+    rs = np.random.RandomState(0)
+    reqs = []
+    for i in range(12):
+        prompt = make_prompt(int(rs.randint(3, 60)), seed=10 + i)
+        n = int(rs.randint(5, 45))
+        kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=99, uid=i, max_tokens=n, ignore_eos=True)
+        reqs.append((i, prompt, kw))
+        tiny_engine.add_request(i, prompt, cond, E.make_sampling(**kw))
+    tiny_engine.run_until_done()
+    for i, prompt, kw in reqs:
+        got, _ = tiny_engine.get_output(i); tiny_engine.release(i)
+        want, _ = tiny_oracle.generate(prompt, cond, oracle.make_sampling(**kw), max_model_len=400)
+        assert [t - 2500 for t in got] == want, f"utterance {i}"
+    st = tiny_engine.stats()
+    assert st.kv_blocks_free == st.kv_blocks_total      # every block returned
+
+
+def test_chunked_prefill_equals_whole(E, tiny_weights, cond):
+    """A row budget smaller than one prompt forces the prompt through several steps; ids must not change."""
+    outs = []
+    for budget in (0, 64):
+        eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=300, max_seqs=2, kv_bytes=1 << 28, max_batched_rows=budget)
+        eng.load_tensors(tiny_weights); eng.finalize()
+        eng.add_request(0, make_prompt(100, seed=4), cond, E.make_sampling(temperature=0.0, max_tokens=12, ignore_eos=True))
+        eng.run_until_done()
+        outs.append(eng.get_output(0)[0]); eng.close()
+    assert outs[0] == outs[1]
+
+
+def test_error_behaviour(E, tiny_engine, cond):
+    sp = E.make_sampling(max_tokens=4)
+    with pytest.raises(ValueError):
+        tiny_engine.add_request(7, [1, 2, 3], cond, sp)                       # not the 695..696..697 layout
+    with pytest.raises(ValueError):
+        tiny_engine.add_request(7, make_prompt(390, seed=1), cond, sp)        # does not fit max_model_len
+    bad = make_prompt(10, seed=1); bad[40] = 5000
+    with pytest.raises(ValueError):
+        tiny_engine.add_request(7, bad, cond, sp)                             # text id out of range
+    with pytest.raises(ValueError):
+        tiny_engine.add_request(7, make_prompt(10, seed=1), cond[:10], sp)    # wrong conditioning shape
+    assert tiny_engine.num_unfinished() == 0
+
+
+def test_llm_surface(E, cond):
+    """The vLLM-shaped API used at tts.py:445-492."""
+    from chatterbox_vllm2_amd import LLM, SamplingParams
+    llm = LLM(model="./t3-model", task="generate", tokenizer="EnTokenizer", tokenizer_mode="custom", gpu_memory_utilization=0.2,
+              enforce_eager=True, max_model_len=200, max_num_seqs=4, load_format="dummy", num_hidden_layers=2)
+    text = make_prompt(10, seed=3)[34:-1]
+    res = llm.generate([{"prompt_token_ids": text, "multi_modal_data": {"conditionals": [cond]}}] * 3,
+                       sampling_params=SamplingParams(temperature=0.8, stop_token_ids=[6562 + 2500], max_tokens=min(1000, 200), top_p=0.8, repetition_penalty=2.0))
+    assert len(res) == 3
+    for r in res:
+        for o in r.outputs:
+            assert len(o.token_ids) > 0 and min(o.token_ids) >= 2500
+            assert o.finish_reason in ("stop", "length")
+    # same prompt, different uid -> different streams; same uid -> same stream
+    again = llm.generate([{"prompt_token_ids": text, "multi_modal_data": {"conditionals": [cond]}}],
+                         sampling_params=SamplingParams(temperature=0.8, stop_token_ids=[9062], max_tokens=200, top_p=0.8, repetition_penalty=2.0))
+    assert again[0].outputs[0].token_ids == res[0].outputs[0].token_ids
+    with pytest.raises(ValueError):
+        llm.generate(["plain string"], SamplingParams())
+    llm.shutdown()

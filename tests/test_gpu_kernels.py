@@ -1,0 +1,153 @@
+"""Kernel-level parity: each HIP kernel, called through the C ABI (t3k_*), against the oracle's function
+of the same name on the same seeded inputs.  Bar: BIT-EXACT (tolerance 0) -- the numerics contract
+ fixes every rounding point and summation order."""
+import numpy as np
+import pytest
+import torch
+
+from util import assert_bit_equal, rand_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    from chatterbox_vllm2_amd import engine
+    engine.load_library()
+    return engine
+
+
+def test_expf_bit_exact(E, oracle):
+    x = torch.cat([torch.linspace(-90, 89, 20001), torch.randn(20000) * 10, torch.tensor([0.0, -0.0, -87.0, -87.0001, 88.0, 88.5, float("-inf")])])
+    got = E.k_expf(x)
+    want = torch.tensor([oracle.expf(float(v)) for v in x.tolist()], dtype=torch.float32)
+    assert_bit_equal(got, want, "expf")
+    # and the contract exp is a good exp: <= 2 ulp from the correctly rounded value on the softmax domain
+    xs = x[(x > -80) & (x < 80)]
+    ref = torch.exp(xs.double())
+    rel = ((E.k_expf(xs).double() - ref).abs() / ref).max().item()
+    assert rel < 3e-7, rel
+
+
+@pytest.mark.parametrize("M,K,N,mt", [(2, 1024, 3072, 0), (1, 1024, 48, 1), (16, 1024, 1024, 0), (17, 1024, 64, 2),
+                                        (64, 1024, 3072, 0), (64, 1024, 1024, 1), (64, 4096, 1024, 0), (64, 1024, 8194, 4),
+                                        (200, 1024, 512, 8), (256, 4096, 256, 4), (33, 128, 16, 0)])
+def test_gemm_bit_exact(E, oracle, M, K, N, mt):
+    x = rand_bf16(M, K, seed=M + K); W = rand_bf16(N, K, seed=N, scale=0.05)
+    got = E.k_gemm(x, W, mt)
+    want = oracle.gemm(x, W)
+    assert_bit_equal(got, want, f"gemm {M}x{K}x{N} mt={mt}")
+    # sanity against plain fp32 matmul (tolerance: reassociation error only)
+    ref = x.float() @ W.float().T
+    assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_wide_dynamic_range(E, oracle):
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(32, 1024, generator=g) * torch.exp2(torch.randint(-12, 12, (32, 1024), generator=g).float())).to(torch.bfloat16)
+    W = (torch.randn(64, 1024, generator=g) * torch.exp2(torch.randint(-12, 12, (64, 1024), generator=g).float())).to(torch.bfloat16)
+    assert_bit_equal(E.k_gemm(x, W), oracle.gemm(x, W), "gemm wide range")
+
+
+@pytest.mark.parametrize("rows", [1, 3, 64, 257])
+def test_rmsnorm_bit_exact(E, oracle, rows):
+    x = rand_bf16(rows, 1024, seed=rows, scale=3.0); w = rand_bf16(1024, seed=9) + 1.0
+    w = w.to(torch.bfloat16)
+    assert_bit_equal(E.k_rmsnorm(x, w), oracle.rmsnorm(x, w), "rmsnorm")
+
+
+@pytest.mark.parametrize("M", [2, 40])
+def test_gate_up_silu_bit_exact(E, oracle, M):
+    Fd = 512
+    x = rand_bf16(M, 1024, seed=1); Wg = rand_bf16(Fd, 1024, seed=2, scale=0.1); Wu = rand_bf16(Fd, 1024, seed=3, scale=0.1)
+    got = E.k_silu_mul_gemm(x, Wg, Wu)
+    g = oracle.gemm(x, Wg).to(torch.bfloat16); u = oracle.gemm(x, Wu).to(torch.bfloat16)
+    assert_bit_equal(got, oracle.silu_mul(g, u), "silu(gate)*up")
+
+
+def _oracle_rope_attention(oracle, qkv, row_stream, row_pos, n_streams, max_pos):
+    cos_t, sin_t = oracle.rope_table(max_pos)
+    pos = torch.tensor(row_pos, dtype=torch.int32)
+    q = oracle.rope(qkv[:, :1024], pos, cos_t, sin_t)
+    k = oracle.rope(qkv[:, 1024:2048], pos, cos_t, sin_t)
+    v = qkv[:, 2048:].contiguous()
+    K = torch.zeros(n_streams, max_pos, 1024, dtype=torch.bfloat16); Vv = torch.zeros_like(K)
+    for r, (s, p) in enumerate(zip(row_stream, row_pos)):
+        K[s, p] = k[r]; Vv[s, p] = v[r]
+    out = torch.empty(len(row_pos), 1024, dtype=torch.bfloat16)
+    for r, (s, p) in enumerate(zip(row_stream, row_pos)):
+        for h in range(16):
+            out[r, h * 64:(h + 1) * 64] = oracle.attn_row(q[r, h * 64:(h + 1) * 64], K[s, :p + 1, h * 64:(h + 1) * 64], Vv[s, :p + 1, h * 64:(h + 1) * 64])
+    return out
+
+
+@pytest.mark.parametrize("lens", [[1], [64], [65], [5, 130, 63, 200], [300, 2]])
+def test_rope_paged_attention_bit_exact(E, oracle, lens):
+    """Prefill-shaped call: every position of every stream is a row (ragged lengths, partial last chunk)."""
+    row_stream, row_pos = [], []
+    for s, L in enumerate(lens):
+        row_stream += [s] * L; row_pos += list(range(L))
+    qkv = rand_bf16(len(row_pos), 3072, seed=sum(lens))
+    max_pos = max(lens) + 3
+    got = E.k_rope_attention(qkv, row_stream, row_pos, len(lens), max_pos)
+    want = _oracle_rope_attention(oracle, qkv, row_stream, row_pos, len(lens), max_pos)
+    assert_bit_equal(got, want, f"attention lens={lens}")
+
+
+def test_attention_peaky_scores(E, oracle):
+    """Large-magnitude q/k: softmax saturates, exp underflows to 0 for most keys (rule-26 style forcing input)."""
+    L = 150
+    qkv = rand_bf16(L, 3072, seed=3, scale=6.0)
+    got = E.k_rope_attention(qkv, [0] * L, list(range(L)), 1, L)
+    want = _oracle_rope_attention(oracle, qkv, [0] * L, list(range(L)), 1, L)
+    assert_bit_equal(got, want, "attention peaky")
+
+
+SAMPLING_CASES = [
+    dict(temperature=0.0),
+    dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0),
+    dict(temperature=0.8, top_p=1.0, repetition_penalty=2.0),
+    dict(temperature=1.3, top_k=40),
+    dict(temperature=0.7, top_k=5, top_p=0.5, min_p=0.05, repetition_penalty=1.2, presence_penalty=0.1, frequency_penalty=0.2),
+    dict(temperature=0.5, min_p=0.2),
+    dict(temperature=2.0, top_p=0.05),
+]
+
+
+@pytest.mark.parametrize("kw", SAMPLING_CASES)
+def test_sampler_bit_exact(E, oracle, kw):
+    g = torch.Generator().manual_seed(11)
+    for trial in range(6):
+        logits2 = (torch.randn(2, 8208, generator=g) * (0.7 + trial)).to(torch.bfloat16)
+        counts = torch.zeros(8194, dtype=torch.int32)
+        counts[torch.randint(0, 8194, (50,), generator=g)] = torch.randint(1, 4, (50,), generator=g).int()
+        counts_gpu = counts.to(torch.uint16).clone()
+        spo = oracle.make_sampling(seed=1234 + trial, uid=7 * trial, **kw)
+        spe = E.make_sampling(seed=1234 + trial, uid=7 * trial, **kw)
+        for step in (0, 1, 77):
+            tok, lg = E.k_sample(logits2, counts_gpu.clone(), spe, 0.5, step)
+            lc, lu = logits2[0, :8194].float(), logits2[1, :8194].float()
+            cfg = (lc + (0.5 * (lc - lu).to(torch.bfloat16).float()).to(torch.bfloat16).float()).to(torch.bfloat16).float()
+            assert_bit_equal(lg, cfg, "CFG logits")
+            want = oracle.sample(cfg, counts, spo, step)
+            assert tok == want, (kw, trial, step, tok, want)
+
+
+def test_sampler_ties_and_degenerate(E, oracle):
+    """bf16 logits tie constantly; all-equal logits and a single dominant logit are the edge cases."""
+    for fill, spike in ((0.0, None), (1.0, (4321, 30.0)), (-3.0, (0, 1.0))):
+        l = torch.full((2, 8208), fill).to(torch.bfloat16)
+        if spike:
+            l[0, spike[0]] = spike[1]; l[1, spike[0]] = spike[1]
+        for kw in (dict(temperature=0.0), dict(temperature=1.0, top_p=0.3), dict(temperature=1.0, top_k=3), dict(temperature=1.0)):
+            counts = torch.zeros(8194, dtype=torch.uint16)
+            tok, lg = E.k_sample(l, counts, E.make_sampling(seed=3, uid=1, **kw), 0.5, 5)
+            want = oracle.sample(lg, torch.zeros(8194, dtype=torch.int32), oracle.make_sampling(seed=3, uid=1, **kw), 5)
+            assert tok == want, (fill, spike, kw, tok, want)
+
+
+def test_sampler_counts_update(E):
+    l = torch.zeros(2, 8208).to(torch.bfloat16); l[:, 100] = 9.0
+    counts = torch.zeros(8194, dtype=torch.uint16)
+    tok, _ = E.k_sample(l, counts, E.make_sampling(temperature=0.0), 0.5, 0)
+    assert tok == 100 and int(counts[100]) == 1 and int(counts.to(torch.int32).sum()) == 1
