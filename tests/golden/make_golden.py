@@ -1,0 +1,145 @@
+"""Generates the committed golden fixtures under tests/golden/ (run in the BUILD container, where
+/root/reference is mounted; the GPU box only sees the resulting .npz / .json files).
+
+    python tests/golden/make_golden.py
+
+What comes from where:
+  G1  cond_enc.npz     -- output of the REFERENCE's own T3CondEnc (+Perceiver, LearnedPositionEmbeddings),
+                          imported from /root/reference with stub parent packages (the package
+                          __init__ files import vllm, which is not installed), seeded weights + inputs.
+  G3  rope.npz         -- inv_freq and cos/sin of transformers' LlamaRotaryEmbedding for the reference's
+                          t3-model/config.json rope settings.
+  G5/G6 streams.npz    -- oracle token streams + post-CFG logits on seeded synthetic weights
+                          (2-layer English, 2-layer multilingual batch, 30-layer short) -- regression
+                          pins for both the oracle and the GPU engine.
+  G7  tokenizer.json   -- token ids of the fixed en/es utterances from the reference's
+                          tokenizer JSON files via the `tokenizers` library.
+No reference source text is stored: only inputs and numeric outputs.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+REF_PKG = os.path.join(REF, "src", "chatterbox_vllm")
+
+EN_TEXT = "The quick brown fox jumps over the lazy dog near the river bank while seven birds sing sweetly in tall trees."
+ES_TEXT = "El rápido zorro marrón salta sobre el perro perezoso cerca del río mientras siete pájaros cantan dulcemente en los árboles altos."
+
+
+def import_reference_leaf_modules():
+    """Stub the parent packages so that the vllm-importing __init__ files are bypassed."""
+    import importlib
+    for name, path in [("chatterbox_vllm", REF_PKG), ("chatterbox_vllm.models", REF_PKG + "/models"),
+                       ("chatterbox_vllm.models.t3", REF_PKG + "/models/t3"),
+                       ("chatterbox_vllm.models.t3.modules", REF_PKG + "/models/t3/modules")]:
+        m = types.ModuleType(name); m.__path__ = [path]; sys.modules[name] = m
+    cfg = importlib.import_module("chatterbox_vllm.models.t3.modules.t3_config")
+    lpe = importlib.import_module("chatterbox_vllm.models.t3.modules.learned_pos_emb")
+    ce = importlib.import_module("chatterbox_vllm.models.t3.modules.cond_enc")
+    return cfg, lpe, ce
+
+
+def g1_cond_enc():
+    cfg, lpe, ce = import_reference_leaf_modules()
+    torch.manual_seed(42)
+    hp = cfg.T3Config.multilingual()
+    enc = ce.T3CondEnc(hp).eval()
+    speech_emb = torch.nn.Embedding(hp.speech_tokens_dict_size, hp.n_channels)
+    pos = lpe.LearnedPositionEmbeddings(hp.max_speech_tokens + 2 + 2, hp.n_channels)
+    spk = torch.randn(1, hp.speaker_embed_size)
+    toks = torch.randint(0, 6561, (1, hp.speech_cond_prompt_len))
+    with torch.no_grad():
+        prompt_emb = speech_emb(toks)[0] + pos(toks)           # tts.py:277
+        out = enc(ce.T3Cond(speaker_emb=spk, cond_prompt_speech_tokens=toks, cond_prompt_speech_emb=prompt_emb,
+                            emotion_adv=0.5 * torch.ones(1, 1)))
+        out_exag = enc.emotion_adv_fc(0.9 * torch.ones(1, 1))   # tts.py:294-296
+        fixed = pos.get_fixed_embedding(torch.tensor([0, 1, 7]))
+    assert tuple(out.shape) == (34, 1024)
+    np.savez_compressed(os.path.join(HERE, "cond_enc.npz"), cond_emb=out.numpy(), emotion_row_09=out_exag.numpy(),
+                        pos_rows_0_1_7=fixed.numpy(), pos_table_rows=pos.emb.weight[[0, 1, 7]].detach().numpy(),
+                        n_params=np.int64(sum(p.numel() for p in enc.parameters())),
+                        constants=np.array([hp.start_speech_token, hp.stop_speech_token, hp.speech_tokens_dict_size,
+                                            hp.max_text_tokens, hp.max_speech_tokens, hp.speech_cond_prompt_len,
+                                            hp.n_channels, hp.text_tokens_dict_size, cfg.T3Config.english_only().text_tokens_dict_size]))
+    print("G1 cond_enc:", out.shape, float(out.abs().mean()))
+
+
+def g3_rope():
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
+    c = json.load(open(os.path.join(REF, "t3-model", "config.json")))
+    cfg = LlamaConfig(hidden_size=1024, num_attention_heads=c["num_attention_heads"], head_dim=c["head_dim"],
+                      rope_theta=c["rope_theta"], rope_scaling=c["rope_scaling"], max_position_embeddings=c["max_position_embeddings"])
+    rot = LlamaRotaryEmbedding(cfg)
+    pos = torch.tensor([[0, 1, 107, 999]])
+    cos, sin = rot(torch.zeros(1, 4, 1024), pos)
+    np.savez_compressed(os.path.join(HERE, "rope.npz"), inv_freq=rot.inv_freq.numpy(), positions=pos.numpy()[0],
+                        cos=cos[0, :, :32].numpy(), sin=sin[0, :, :32].numpy(),
+                        llama_cfg=np.array([c["num_hidden_layers"], c["num_attention_heads"], c["num_key_value_heads"], c["head_dim"],
+                                            c["intermediate_size"], c["vocab_size"]]), rms_eps=np.float64(c["rms_norm_eps"]))
+    print("G3 rope inv_freq[15:18]:", rot.inv_freq[15:18].tolist())
+
+
+def g7_tokenizer():
+    from chatterbox_vllm2_amd.prompt import TextTokenizer
+    en = TextTokenizer("EnTokenizer", os.path.join(REF_PKG, "models/t3/tokenizer.json"))
+    mtl = TextTokenizer("MtlTokenizer", os.path.join(REF_PKG, "models/t3/grapheme_mtl_merged_expanded_v1.json"))
+    out = {
+        "en_text": EN_TEXT, "es_text": ES_TEXT,
+        "en_english_ids": en.encode("[START]" + EN_TEXT + "[STOP]"),                 # tts.py:435
+        "en_mtl_ids": mtl.encode("<en>[START]" + EN_TEXT + "[STOP]"),                # tts.py:441
+        "es_mtl_ids": mtl.encode("<es>[START]" + ES_TEXT + "[STOP]"),
+        "en_vocab": en.vocab_size, "mtl_vocab": mtl.vocab_size,
+        "special": {k: en.tok.token_to_id(k) for k in ("[START]", "[STOP]", "[SPACE]", "[UNK]", "[PLACEHOLDER55]", "[PLACEHOLDER56]", "[PLACEHOLDER57]")},
+        "lang": {k: mtl.tok.token_to_id(k) for k in ("[en]", "[es]", "[fr]", "[zh]")},
+    }
+    json.dump(out, open(os.path.join(HERE, "tokenizer.json"), "w"), indent=1, ensure_ascii=False)
+    print("G7 tokenizer: en", len(out["en_english_ids"]), "en/mtl", len(out["en_mtl_ids"]), "es/mtl", len(out["es_mtl_ids"]))
+
+
+def g6_streams():
+    from oracle import oracle as O
+    from chatterbox_vllm2_amd.prompt import assemble_prompt_ids
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb, synthetic_tensors
+    tok = json.load(open(os.path.join(HERE, "tokenizer.json")))
+    cond = synthetic_cond_emb(1)
+    out = {}
+    # (a) 2-layer English, C1 prompt (T = 108): greedy + the reference's sampling defaults
+    m = O.OracleModel(2, 704, max_pos=400).load(synthetic_tensors(2, 704, 1234))
+    p_en = assemble_prompt_ids(tok["en_english_ids"])
+    ids, lg = m.generate(p_en, cond, O.make_sampling(temperature=0.0, max_tokens=64, ignore_eos=True), want_logits=True, max_model_len=400)
+    out["l2_en_greedy_ids"] = np.array(ids, np.int32); out["l2_en_greedy_logits_step0"] = lg[0].numpy(); out["l2_en_greedy_logits_step63"] = lg[63].numpy()
+    ids, _ = m.generate(p_en, cond, O.make_sampling(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, uid=0, max_tokens=64, ignore_eos=True), max_model_len=400)
+    out["l2_en_sampled_ids"] = np.array(ids, np.int32)
+    m.close()
+    # (b) 2-layer multilingual: en (T=116) and es (T=141), uid 0/1, sampled
+    m = O.OracleModel(2, 2454, max_pos=400).load(synthetic_tensors(2, 2454, 1234))
+    for name, key, uid in (("en", "en_mtl_ids", 0), ("es", "es_mtl_ids", 1)):
+        ids, _ = m.generate(assemble_prompt_ids(tok[key]), cond, O.make_sampling(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, uid=uid, max_tokens=48, ignore_eos=True), max_model_len=400)
+        out[f"l2_mtl_{name}_sampled_ids"] = np.array(ids, np.int32)
+    m.close()
+    # (c) 30-layer English (the real depth), C1 prompt, 16 greedy + 16 sampled tokens
+    m = O.OracleModel(30, 704, max_pos=200).load(synthetic_tensors(30, 704, 1234))
+    ids, lg = m.generate(p_en, cond, O.make_sampling(temperature=0.0, max_tokens=16, ignore_eos=True), want_logits=True, max_model_len=200)
+    out["l30_en_greedy_ids"] = np.array(ids, np.int32); out["l30_en_greedy_logits_step0"] = lg[0].numpy()
+    ids, _ = m.generate(p_en, cond, O.make_sampling(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, uid=0, max_tokens=16, ignore_eos=True), max_model_len=200)
+    out["l30_en_sampled_ids"] = np.array(ids, np.int32)
+    m.close()
+    np.savez_compressed(os.path.join(HERE, "streams.npz"), **out)
+    print("G6 streams:", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g3", "g7", "g6"]
+    if "g1" in which: g1_cond_enc()
+    if "g3" in which: g3_rope()
+    if "g7" in which: g7_tokenizer()
+    if "g6" in which: g6_streams()
