@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- T3 decode throughput on MI355X (BASELINE.json metric: speech-tokens/s/GPU, batch 32, + p50 RTF).
+
+Workload (config.workload = "C3"): multilingual vocab 2454, B = 32 utterances per GPU = 16 en prompts
+(T = 116) + 16 es prompts (T = 141), max_model_len = 1000, real layer count (30), bf16 weights, seeded
+synthetic weights (no checkpoint offline), the reference's sampling defaults (temperature 0.8, top-p 0.8,
+repetition penalty 2.0, tts.py:377,416) with the stop id masked (fixed-length generation).
+A "step" = one pass of the hot path over the batch = one decode step of all 32 utterances (64 CFG rows).
+Prefill and warmup steps are outside the timed region; inputs (weights, prompts, KV) are resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable copy rate)
+KV_BYTES_TOK_STREAM_LAYER = 2 * 16 * 64 * 2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=800)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--layers", type=int, default=30)
+    ap.add_argument("--max-model-len", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    return ap.parse_args()
+
+
+def build_requests(E, args, rank):
+    from chatterbox_vllm2_amd.prompt import assemble_prompt_ids
+    tok = json.load(open(os.path.join(ROOT, "tests", "golden", "tokenizer.json")))
+    p_en, p_es = assemble_prompt_ids(tok["en_mtl_ids"]), assemble_prompt_ids(tok["es_mtl_ids"])
+    reqs = []
+    for i in range(args.batch):
+        prompt = p_en if i < args.batch // 2 else p_es
+        uid = rank * args.batch + i                       # global utterance id: shards are disjoint
+        sp = E.make_sampling(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, uid=uid,
+                             max_tokens=args.max_model_len - len(prompt), ignore_eos=True)
+        reqs.append((i, prompt, sp))
+    return reqs
+
+
+def run_pass(eng, reqs, cond, warmup, steps, sync, profile=False):
+    """prefill (untimed) -> warmup decode steps -> barrier -> K timed decode steps -> barrier.  Returns dict."""
+    import torch
+    for rid, prompt, sp in reqs:
+        eng.add_request(rid, prompt, cond, sp)
+    t0 = time.perf_counter()
+    n_pref = 0
+    while True:                                          # prefill steps (all prompts) until every utterance decodes
+        r = eng.step(); n_pref += 1
+        if r.n_prefill_rows == 0 or r.n_waiting == 0 and r.n_sampled == len(reqs):
+            break
+    torch.cuda.synchronize()
+    prefill_s = time.perf_counter() - t0
+    assert eng.run_steps(warmup) == warmup
+    eng.set_profile(profile)
+    eng.reset_stats()
+    sync()
+    t0 = time.perf_counter()
+    done = eng.run_steps(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sync()
+    eng.set_profile(False)
+    assert done == steps, f"only {done} of {steps} steps ran (steps + warmup must stay below max_model_len - longest prompt)"
+    st = eng.stats()
+    assert st.decode_steps == steps and st.tokens_generated == steps * len(reqs)
+    kern = {k: eng.kernel_ms(k) for k in __import__("chatterbox_vllm2_amd.engine", fromlist=["x"]).KERNEL_CLASSES} if profile else {}
+    # drain: finish the utterances quickly (not timed) so the engine is reusable
+    eng.run_until_done()
+    for rid, _, _ in reqs:
+        eng.release(rid)
+    return dict(dt=dt, prefill_s=prefill_s, prefill_steps=n_pref, stats=st, kern=kern)
+
+
+def cpu_baseline(weights, args):
+    """The oracle (a port, kind="port") timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    ncores = os.cpu_count() or 1
+    B, ctx, steps = args.batch, 500, 4
+    m = O.OracleModel(args.layers, 2454, max_pos=ctx + steps + 2, n_streams=2 * B).load(weights)
+    m.decode_steps_timing(1, ctx, 1)                     # touch the weights once
+    t0 = time.perf_counter()
+    m.decode_steps_timing(B, ctx, steps)
+    dt = time.perf_counter() - t0
+    m.close()
+    return {"value": round(B * steps / dt, 3), "unit": "speech-tokens/s", "cores": ncores, "kind": "port",
+            "sample": f"C oracle (OpenMP, {ncores} threads): {steps} decode steps of the same B={B} batch (64 CFG rows, {args.layers} layers) "
+                      f"at context {ctx}, weights resident in RAM; {dt:.1f} s of CPU work"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs one rank per GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
+                     f"--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus {args.gpus} ...")
+        sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the T3 engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    from chatterbox_vllm2_amd import engine as E
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb, synthetic_tensors
+
+    longest = 141
+    if args.steps + args.warmup > args.max_model_len - longest - 3:
+        sys.exit(f"steps + warmup must be <= {args.max_model_len - longest - 3} for this workload")
+    weights = list(synthetic_tensors(args.layers, 2454, 1234))
+    cond = synthetic_cond_emb(1)
+    eng = E.T3Engine(n_layers=args.layers, text_vocab=2454, max_model_len=args.max_model_len, max_seqs=args.batch,
+                     device_id=local_rank, gpu_memory_utilization=0.5, max_batched_rows=8192)
+    eng.load_tensors(weights); eng.finalize()
+    reqs = build_requests(E, args, rank)
+
+    res = run_pass(eng, reqs, cond, args.warmup, args.steps, sync, profile=False)
+    t = torch.tensor([res["dt"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    st = res["stats"]
+
+    prof = None
+    if rank == 0 and not args.no_profile_pass:
+        prof = run_pass(eng, reqs, cond, args.warmup, args.steps, lambda: torch.cuda.synchronize(), profile=True)
+    if world > 1:
+        dist.barrier()
+    eng.close()
+
+    if rank == 0:
+        total_tokens = world * args.batch * args.steps
+        value = total_tokens / dt
+        bytes_step = st.algo_bytes_decode / st.decode_steps
+        out = {
+            "metric": "speech-tokens/sec/GPU (T3 decode, batch=32) + p50 RTF", "value": round(value, 2), "unit": "speech-tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "C3: t3-model-multilingual (30-layer Llama_520M, vocab 2454), 16 en (T=116) + 16 es (T=141) utterances per GPU, "
+                                   "max_model_len=1000, CFG dual stream (64 rows/step), temperature 0.8 / top-p 0.8 / repetition penalty 2.0, stop id masked",
+                       "batch_per_gpu": args.batch, "global_batch": world * args.batch, "max_model_len": args.max_model_len,
+                       "layers": args.layers, "parallelism": f"dp{world} (utterance shards, no collective inside a step)",
+                       "weights": "seeded synthetic N(0,0.02^2), seed 1234"},
+            "tokens_per_s_per_gpu": round(value / world, 2),
+            "rtf_p50": round((dt / args.steps) * 25.0, 5),      # every utterance emits one token per step: wall / (tokens/25)
+            "prefill_ms": round(res["prefill_s"] * 1e3, 2), "prefill_steps": res["prefill_steps"],
+            "mean_ctx": round(st.sum_ctx_decode / st.decode_rows, 1),
+            "step_roofline": {"bound": "hbm", "algo_bytes_per_step": round(bytes_step), "achieved": round(bytes_step / (dt / args.steps) / 1e9, 1),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+        }
+        if prof:
+            kern = prof["kern"]; pst = prof["stats"]
+            tot = {k: v[0] * v[1] for k, v in kern.items()}
+            dom = max(tot, key=tot.get)
+            wbytes = {"gemm_qkv": 3072 * 1024 * 2, "gemm_o": 1024 * 1024 * 2, "gemm_gateup": 8192 * 1024 * 2, "gemm_down": 4096 * 1024 * 2,
+                      "gemm_head": 8194 * 1024 * 2}
+            if dom == "attention":      # KV read of one layer: sum over the 2B rows of ctx * 4096 B (SURVEY 8d per-unit figure / 30 layers)
+                algo = pst.sum_ctx_decode / pst.decode_steps * KV_BYTES_TOK_STREAM_LAYER
+            else:
+                algo = wbytes.get(dom, 0)
+            ms = kern[dom][0]
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tf):
+                traffic = json.load(open(tf)).get(dom)
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "algo_bytes_per_launch": round(algo), "avg_launch_ms": round(ms, 5), "launches": kern[dom][1]}
+            out["kernel_ms_per_step"] = {k: round(tot[k] / pst.decode_steps, 4) for k in tot}
+            out["profiled_ms_per_step"] = round(prof["dt"] / args.steps * 1e3, 4)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(weights, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

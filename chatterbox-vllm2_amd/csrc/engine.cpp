@@ -550,6 +550,19 @@ extern "C" int t3_run_until_done(T3Handle e) {
     return T3_OK;
 }
 
+extern "C" int t3_run_steps(T3Handle e, int32_t n, int32_t* done) {
+    if (!e) return T3_E_INVALID;
+    T3StepResult r;
+    int k = 0;
+    for (; k < n && t3_num_unfinished(e) > 0; ++k) {
+        int rc = t3_step(e, &r);
+        if (rc) { if (done) *done = k; return rc; }
+        if (r.n_rows == 0) break;
+    }
+    if (done) *done = k;
+    return T3_OK;
+}
+
 extern "C" int t3_get_output(T3Handle e, int64_t req_id, int32_t* ids, int32_t* n, int32_t* finish_reason) {
     if (!e || !n) return T3_E_INVALID;
     auto it = e->reqs.find(req_id);

@@ -60,7 +60,7 @@ class T3Stats(ct.Structure):
 # every symbol include/t3_engine.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
     "t3_create", "t3_destroy", "t3_last_error", "t3_load_tensor", "t3_finalize_weights", "t3_add_request",
-    "t3_step", "t3_run_until_done", "t3_num_unfinished", "t3_get_output", "t3_release_request",
+    "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_release_request",
     "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_kernel_ms",
     "t3k_gemm", "t3k_rmsnorm", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_sample", "t3k_expf",
 ]
@@ -97,6 +97,7 @@ def load_library():
     L.t3_add_request.argtypes = [vp, i64, vp, i32, vp, ct.POINTER(T3Sampling)]
     L.t3_step.argtypes = [vp, ct.POINTER(T3StepResult)]
     L.t3_run_until_done.argtypes = [vp]
+    L.t3_run_steps.argtypes = [vp, i32, ct.POINTER(i32)]
     L.t3_num_unfinished.argtypes = [vp]
     L.t3_get_output.argtypes = [vp, i64, vp, ct.POINTER(i32), ct.POINTER(i32)]
     L.t3_release_request.argtypes = [vp, i64]
@@ -205,6 +206,11 @@ class T3Engine:
 
     def run_until_done(self):
         self._chk(self.lib.t3_run_until_done(self.h))
+
+    def run_steps(self, n: int) -> int:
+        done = ct.c_int32(0)
+        self._chk(self.lib.t3_run_steps(self.h, int(n), ct.byref(done)))
+        return int(done.value)
 
     def num_unfinished(self) -> int:
         return int(self.lib.t3_num_unfinished(self.h))

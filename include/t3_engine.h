@@ -117,6 +117,8 @@ int t3_add_request(T3Handle h, int64_t req_id, const int32_t* prompt_ids, int32_
                    const float* cond_emb, const T3Sampling* sampling);
 int t3_step(T3Handle h, T3StepResult* res);      /* admit -> prefill/decode rows -> sample, once */
 int t3_run_until_done(T3Handle h);               /* C++ loop, no Python per step */
+/* Runs at most n steps (stops early when nothing is left); *done = steps actually run. */
+int t3_run_steps(T3Handle h, int32_t n, int32_t* done);
 int t3_num_unfinished(T3Handle h);
 /* ids: offset-space token ids (>= 2500), the stop id included when hit.
  * On entry *n = capacity; on exit *n = number of tokens.  finish_reason: 0 running, 1 stop, 2 length. */

@@ -1,0 +1,168 @@
+"""CPU tests of the oracle: pinned against (a) the reference's importable leaf modules via committed goldens,
+(b) transformers' Llama implementation, (c) published known-answer vectors, (d) its own committed token streams."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import make_prompt
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_philox_known_answers(oracle):
+    # Random123 kat_vectors: philox4x32-10
+    assert oracle.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_contract_exp_accuracy(oracle):
+    xs = np.concatenate([np.linspace(-87, 88, 5001), np.random.RandomState(0).randn(2000) * 5]).astype(np.float32)
+    got = np.array([oracle.expf(float(x)) for x in xs], dtype=np.float64)
+    ref = np.exp(xs.astype(np.float64))
+    assert np.max(np.abs(got - ref) / ref) < 3e-7          # ~2 ulp
+    assert oracle.expf(0.0) == 1.0 and oracle.expf(-100.0) == 0.0 and oracle.expf(float("-inf")) == 0.0
+
+
+def test_rope_table_vs_hf_golden(oracle):
+    g = np.load(os.path.join(G, "rope.npz"))
+    cos_t, sin_t = oracle.rope_table(1000)
+    for r, p in enumerate(g["positions"]):
+        # HF computes angle, cos and sin in fp32; the oracle in double then rounds to bf16: agree to bf16 resolution
+        assert np.max(np.abs(cos_t[p].numpy() - g["cos"][r])) < 2 ** -8
+        assert np.max(np.abs(sin_t[p].numpy() - g["sin"][r])) < 2 ** -8
+    # llama3 scaling: the three interpolated frequencies of SURVEY.md A.3
+    assert np.allclose(g["inv_freq"][15:18], [1.3718937e-3, 5.2484606e-4, 1.7850779e-4], rtol=1e-6)
+    assert list(g["llama_cfg"]) == [30, 16, 16, 64, 4096, 8]
+
+
+def test_reference_constants_golden():
+    """Constants read from the REFERENCE's T3Config (imported when the golden was made) equal the product's."""
+    from chatterbox_vllm2_amd import constants as C
+    c = np.load(os.path.join(G, "cond_enc.npz"))["constants"]
+    assert list(c) == [C.START_SPEECH_TOKEN, C.STOP_SPEECH_TOKEN, C.SPEECH_VOCAB, 2048, 4096, 150, C.HIDDEN, C.TEXT_VOCAB_MTL, C.TEXT_VOCAB_EN]
+    z = np.load(os.path.join(G, "cond_enc.npz"))
+    assert z["cond_emb"].shape == (34, 1024) and int(z["n_params"]) == 4497408
+    assert np.array_equal(z["pos_rows_0_1_7"][0], z["pos_table_rows"])     # get_fixed_embedding == table rows
+
+
+def test_prompt_embeds_layout(oracle, tiny_weights):
+    """t3.py:542-561: cond rows copied, text rows = text_emb + text_pos (cond) / zeros (uncond), BOS = speech_emb[6561] + speech_pos[0]."""
+    w = dict(tiny_weights)
+    cond = torch.from_numpy(np.load(os.path.join(G, "cond_enc.npz"))["cond_emb"])      # output of the reference's T3CondEnc
+    m = oracle.OracleModel(2, 704, max_pos=128).load(tiny_weights)
+    prompt = make_prompt(9, seed=0)
+    ec, eu = m.prompt_embeds(prompt, cond)
+    T = len(prompt)
+    assert torch.equal(ec[:34], cond.to(torch.bfloat16)) and torch.equal(eu[:34], ec[:34])
+    for i in range(34, T - 1):
+        want = (w["text_emb.weight"][prompt[i]].float() + w["text_pos_emb.emb.weight"][i - 34].float()).to(torch.bfloat16)
+        assert torch.equal(ec[i], want) and not eu[i].any()
+    bos = (w["speech_emb.weight"][6561].float() + w["speech_pos_emb.emb.weight"][0].float()).to(torch.bfloat16)
+    assert torch.equal(ec[T - 1], bos) and torch.equal(eu[T - 1], bos)
+    with pytest.raises(ValueError):
+        m.prompt_embeds(prompt[:20], cond)
+
+
+def _hf_model(tensors, n_layers, dtype):
+    from transformers import LlamaConfig, LlamaModel
+    cfg = LlamaConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=n_layers, num_attention_heads=16,
+                      num_key_value_heads=16, head_dim=64, rms_norm_eps=1e-5, rope_theta=500000.0, vocab_size=8,
+                      rope_scaling={"factor": 8.0, "high_freq_factor": 4.0, "low_freq_factor": 1.0,
+                                    "original_max_position_embeddings": 8192, "rope_type": "llama3"},
+                      max_position_embeddings=131072, attention_bias=False, mlp_bias=False, hidden_act="silu",
+                      attn_implementation="eager")
+    hf = LlamaModel(cfg).eval()
+    sd = {k[5:]: v.float() for k, v in tensors if k.startswith("tfmr.")}
+    sd["embed_tokens.weight"] = torch.zeros(8, 1024)
+    hf.load_state_dict(sd)
+    return hf.to(dtype)
+
+
+@pytest.mark.parametrize("n_layers", [2, 6])
+def test_oracle_vs_transformers_llama(oracle, n_layers):
+    """Independent Llama implementation, same weights.  Tolerance: the oracle (bf16 activations, fp32 accumulation)
+    must be as close to HF-fp32 as HF's own bf16 run is (x1.5), and cosine > 0.9995."""
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb, synthetic_tensors
+    tens = list(synthetic_tensors(n_layers, 704, 1234))
+    m = oracle.OracleModel(n_layers, 704, max_pos=128).load(tens)
+    prompt = make_prompt(22, seed=5)
+    ec, _ = m.prompt_embeds(prompt, synthetic_cond_emb(1))
+    T = len(prompt)
+    h, _ = m.forward_rows(ec, [0] * T, list(range(T)))
+    got = oracle.rmsnorm(h, dict(tens)["tfmr.norm.weight"]).float()
+    with torch.no_grad():
+        ref32 = _hf_model(tens, n_layers, torch.float32)(inputs_embeds=ec.float()[None]).last_hidden_state[0]
+        ref16 = _hf_model(tens, n_layers, torch.bfloat16)(inputs_embeds=ec[None]).last_hidden_state[0].float()
+    err_oracle = (got - ref32).abs().mean().item()
+    err_hf_bf16 = (ref16 - ref32).abs().mean().item()
+    cos = torch.nn.functional.cosine_similarity(got.flatten(), ref32.flatten(), dim=0).item()
+    assert cos > 0.9995, cos
+    assert err_oracle < 1.5 * err_hf_bf16 + 1e-4, (err_oracle, err_hf_bf16)
+
+
+def test_gemm_matches_fp32_matmul(oracle):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 1024, generator=g).to(torch.bfloat16); W = (torch.randn(37, 1024, generator=g) * 0.05).to(torch.bfloat16)
+    ref = x.double() @ W.double().T
+    assert (oracle.gemm(x, W).double() - ref).abs().max().item() < 2e-5 * 1024 ** 0.5
+
+
+def test_attention_matches_softmax(oracle):
+    g = torch.Generator().manual_seed(1)
+    for L in (1, 63, 64, 65, 200):
+        q = torch.randn(64, generator=g).to(torch.bfloat16); K = torch.randn(L, 64, generator=g).to(torch.bfloat16); V = torch.randn(L, 64, generator=g).to(torch.bfloat16)
+        ref = torch.softmax((K.double() @ q.double()) / 8.0, 0) @ V.double()
+        got = oracle.attn_row(q, K, V).double()
+        assert (got - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())   # bf16 output rounding
+
+
+def test_sampler_semantics(oracle):
+    V = 8194
+    lg = torch.full((V,), -5.0); lg[10] = 3.0; lg[20] = 2.5; lg[30] = 2.0
+    cnt = torch.zeros(V, dtype=torch.int32)
+    assert oracle.sample(lg, cnt, oracle.make_sampling(temperature=0.0), 0) == 10
+    cnt[10] = 1                                     # repetition penalty 2.0: 3.0 -> 1.5 < 2.5
+    assert oracle.sample(lg, cnt, oracle.make_sampling(temperature=0.0, repetition_penalty=2.0), 0) == 20
+    neg = lg.clone(); neg[10] = -1.0; neg[20] = -1.2; neg[30] = -9.0           # negative logits are multiplied: -1.0 -> -2.0
+    assert oracle.sample(neg, cnt, oracle.make_sampling(temperature=0.0, repetition_penalty=2.0), 0) == 20
+    cnt[:] = 0
+    draws = [oracle.sample(lg, cnt, oracle.make_sampling(temperature=1.0, top_k=2, repetition_penalty=1.0, seed=s), 0) for s in range(200)]
+    assert set(draws) == {10, 20}
+    pk = torch.full((V,), -30.0); pk[10] = 3.0; pk[20] = 2.5; pk[30] = 2.0      # p = 0.506, 0.307, 0.186
+    draws = [oracle.sample(pk, cnt, oracle.make_sampling(temperature=1.0, top_p=0.3, repetition_penalty=1.0, seed=s), 0) for s in range(100)]
+    assert set(draws) == {10}                       # vLLM rule: drop the ascending prefix with cumulative mass <= 1 - top_p = 0.7
+    draws = [oracle.sample(pk, cnt, oracle.make_sampling(temperature=1.0, top_p=0.6, repetition_penalty=1.0, seed=s), 0) for s in range(200)]
+    assert set(draws) == {10, 20}                   # 1 - p = 0.4: only token 30 (0.186) goes
+    draws = [oracle.sample(lg, cnt, oracle.make_sampling(temperature=1.0, min_p=0.7, repetition_penalty=1.0, seed=s), 0) for s in range(100)]
+    assert set(draws) == {10}                       # p(20)/p(10) = e^-0.5 = 0.61 < 0.7
+    # distribution check of the Philox draw: 3 dominant tokens at temperature 1
+    n = 4000
+    draws = np.array([oracle.sample(lg, cnt, oracle.make_sampling(temperature=1.0, repetition_penalty=1.0, seed=1, uid=u), 3) for u in range(n)])
+    p = torch.softmax(lg.double(), 0).numpy()
+    for t in (10, 20, 30):
+        assert abs((draws == t).mean() - p[t]) < 4 * math.sqrt(p[t] * (1 - p[t]) / n)
+    # determinism in (seed, uid, step) only
+    a = oracle.sample(lg, cnt, oracle.make_sampling(temperature=1.0, seed=5, uid=9), 17)
+    assert a == oracle.sample(lg, cnt, oracle.make_sampling(temperature=1.0, seed=5, uid=9), 17)
+
+
+def test_golden_streams_regression(oracle):
+    """The committed token streams (tests/golden/streams.npz) pin the oracle itself against silent change."""
+    from chatterbox_vllm2_amd.prompt import assemble_prompt_ids
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb, synthetic_tensors
+    z = np.load(os.path.join(G, "streams.npz")); tok = json.load(open(os.path.join(G, "tokenizer.json")))
+    cond = synthetic_cond_emb(1)
+    m = oracle.OracleModel(2, 704, max_pos=400).load(synthetic_tensors(2, 704, 1234))
+    p = assemble_prompt_ids(tok["en_english_ids"])
+    assert len(p) == 108                             # C1: T = 108
+    ids, lg = m.generate(p, cond, oracle.make_sampling(temperature=0.0, max_tokens=64, ignore_eos=True), want_logits=True, max_model_len=400)
+    assert ids == z["l2_en_greedy_ids"].tolist()
+    assert np.array_equal(lg[0].numpy().view(np.int32), z["l2_en_greedy_logits_step0"].view(np.int32))
+    assert np.array_equal(lg[63].numpy().view(np.int32), z["l2_en_greedy_logits_step63"].view(np.int32))
+    ids, _ = m.generate(p, cond, oracle.make_sampling(temperature=0.8, top_p=0.8, repetition_penalty=2.0, max_tokens=64, ignore_eos=True), max_model_len=400)
+    assert ids == z["l2_en_sampled_ids"].tolist()
