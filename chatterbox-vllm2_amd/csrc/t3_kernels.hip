@@ -72,18 +72,25 @@ __device__ __forceinline__ uint32_t silu_mul_bf(uint32_t g, uint32_t u) {   // b
 }
 
 // ------------------------------------------------------------------------------------------------
-// Skinny GEMM  y[m][n] = sum_k x[m][k] * W[n][k]   (x, W bf16; exact products; fp32 chains)
+// Skinny GEMM  y[m][n] = sum_k x[m][k] * W[n][k]   (x, W bf16, fp32 accumulation on the matrix cores)
 //
-// Contract order: K is cut into 4 contiguous segments (one per wave of the workgroup); within a
-// segment 32-wide k-blocks ascending; within a block k = 8q + j with j outer, q inner -- exactly the
-// order in which v_mfma_f32_16x16x4_f32 (an fmaf chain over its 4 k values q = 0..3, exact fp32)
-// consumes element j of every lane's 16-byte operand fragment; result = ((p0 + p1) + p2) + p3.
+// Contract order (DESIGN.md "GEMM"): K is cut into 4 contiguous segments (one per wave of the
+// workgroup); a wave folds its segment with a chain of v_mfma_f32_16x16x32_bf16 in ascending k (each
+// instruction folds 4 blocks of 8 consecutive k into the fp32 accumulator; its exact arithmetic was
+// identified on-device and is restated in the checker); result = ((p0 + p1) + p2) + p3 in fp32.
 //
 // One workgroup = 4 waves = NT n-tiles of 16 columns x MT m-tiles of 16 rows.  Weights are packed so
 // that a wave's weight load is one contiguous 1 KiB (pack_weight); activations are read row-major,
-// 16 rows x 64 B per wave instruction (L2-resident, they are tiny next to the weights).
+// 16 rows x 64 B per wave instruction (L2-resident, they are tiny next to the weights).  Both operand
+// streams run through a PD-deep register ring: vmcnt retires in issue order, so the activation loads
+// must be issued as far ahead as the weight loads or they would drain the weight prefetch every step.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, int EPI>
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 as_frag(const uint4& v) {
+    union { uint4 u; bf16x8 f; } c; c.u = v; return c.f;
+}
+
+template <int MT, int NT, int EPI, int PD>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][MT*NT][4 regs][64 lanes]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,35 +113,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    uint4 wc[NT], xc[MT], wn[NT], xn[MT];
+    uint4 wr[PD][NT], xr[PD][MT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wc[t] = wp[t][0];
+    for (int j = 0; j < PD; ++j)
+        if (j < kbs) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) xc[i] = xp[i][0];
-
-    for (int kb = 0; kb < kbs; ++kb) {
-        if (kb + 1 < kbs) {
+            for (int t = 0; t < NT; ++t) wr[j][t] = wp[t][j * 64];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wn[t] = wp[t][(kb + 1) * 64];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) xn[i] = xp[i][(kb + 1) * 4];
+            for (int i = 0; i < MT; ++i) xr[j][i] = xp[i][j * 4];
         }
-#define T3_MFMA_STEP(J)                                                                              \
-        {                                                                                            \
-            float bj[NT], aj[MT];                                                                    \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t) bj[t] = elem<J>(wc[t]);                    \
-            _Pragma("unroll") for (int i = 0; i < MT; ++i) aj[i] = elem<J>(xc[i]);                    \
-            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                            \
-                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                        \
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[i], bj[t], acc[i][t], 0, 0, 0); \
+    for (int kbase = 0; kbase < kbs; kbase += PD) {
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+            const int kb = kbase + j;
+            if (kb < kbs) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(xr[j][i]), as_frag(wr[j][t]), acc[i][t], 0, 0, 0);
+                if (kb + PD < kbs) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) wr[j][t] = wp[t][(kb + PD) * 64];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) xr[j][i] = xp[i][(kb + PD) * 4];
+                }
+            }
         }
-        T3_MFMA_STEP(0) T3_MFMA_STEP(1) T3_MFMA_STEP(2) T3_MFMA_STEP(3)
-        T3_MFMA_STEP(4) T3_MFMA_STEP(5) T3_MFMA_STEP(6) T3_MFMA_STEP(7)
-#undef T3_MFMA_STEP
-#pragma unroll
-        for (int t = 0; t < NT; ++t) wc[t] = wn[t];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) xc[i] = xn[i];
     }
 
     // cross-wave (= cross-segment) reduction in segment order
@@ -188,23 +193,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 int choose_mt(int M, int ntiles_x) {
     const int mtiles = (M + 15) / 16;
     if (const char* e = getenv("T3_GEMM_MT")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) return v; }
-    // largest MT that still leaves >= 2 workgroups per CU, never more than the rows need
-    int best = 1;
-    for (int mt = 8; mt >= 1; mt >>= 1) {
-        if (mt > 1 && mt / 2 >= mtiles) continue;
-        const long wgs = (long)ntiles_x * ((mtiles + mt - 1) / mt);
-        if (wgs >= 512 || mt == 1) { best = mt; break; }
-    }
-    return best;
+    // the weight tile should leave HBM once: let one workgroup cover all rows when it can (M <= 128)
+    (void)ntiles_x;
+    if (mtiles <= 1) return 1;
+    if (mtiles <= 2) return 2;
+    if (mtiles <= 4) return 4;
+    return 8;
 }
 
 template <int MT, int NT, int EPI>
 static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
+    constexpr int PD = (MT + NT) <= 3 ? 8 : (MT + NT) <= 6 ? 8 : 4;     // ring depth, bounded by the register file
     const int ntiles = (a.N + 15) / 16;           // EPI_SILU: N = F -> one workgroup per output tile (2 packed tiles)
     const int gx = (EPI == EPI_SILU) ? ntiles : (ntiles + NT - 1) / NT;
     const int gy = ((a.M + 15) / 16 + MT - 1) / MT;
     const size_t lds = (size_t)4 * MT * NT * 4 * 64 * sizeof(float);
-    hipLaunchKernelGGL((gemm_kernel<MT, NT, EPI>), dim3(gx, gy), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_kernel<MT, NT, EPI, PD>), dim3(gx, gy), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
