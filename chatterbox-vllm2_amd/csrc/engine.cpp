@@ -79,6 +79,7 @@ struct T3Engine {
 
     // activations
     uint16_t *h = nullptr, *xn = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *act = nullptr, *xlast = nullptr, *logits = nullptr;
+    float* part = nullptr;     // [4][rmax][1024] fp32 split-K slabs of o_proj / down_proj
     float* d_cond = nullptr;
     uint16_t* d_counts = nullptr;
     T3Sampling* d_sp = nullptr;
@@ -154,7 +155,7 @@ extern "C" int t3_destroy(T3Handle e) {
     free_dev(e->norm); free_dev(e->text_emb); free_dev(e->speech_emb); free_dev(e->text_pos); free_dev(e->speech_pos); free_dev(e->head);
     free_dev(e->cos_t); free_dev(e->sin_t); free_dev(e->kv); free_dev(e->d_block_table);
     free_dev(e->h); free_dev(e->xn); free_dev(e->qkv); free_dev(e->qrot); free_dev(e->att); free_dev(e->act); free_dev(e->xlast); free_dev(e->logits);
-    free_dev(e->d_cond); free_dev(e->d_counts); free_dev(e->d_sp); free_dev(e->d_dbg); free_dev(e->d_meta);
+    free_dev(e->part); free_dev(e->d_cond); free_dev(e->d_counts); free_dev(e->d_sp); free_dev(e->d_dbg); free_dev(e->d_meta);
     if (e->h_meta) (void)hipHostFree(e->h_meta);
     if (e->h_out_tok) (void)hipHostFree(e->h_out_tok);
     for (int k = 0; k < K_COUNT; ++k) for (auto& p : e->pev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -299,6 +300,7 @@ extern "C" int t3_finalize_weights(T3Handle e) {
     if ((rc = dalloc(e, &e->qrot, R * D, true))) return rc;
     if ((rc = dalloc(e, &e->att, R * D, true))) return rc;
     if ((rc = dalloc(e, &e->act, R * F, true))) return rc;
+    if ((rc = dalloc(e, &e->part, 4 * R * D, true))) return rc;
     if ((rc = dalloc(e, &e->xlast, 2 * S * D, true))) return rc;
     if ((rc = dalloc(e, &e->logits, 2 * S * VPAD, true))) return rc;
     if ((rc = dalloc(e, &e->d_cond, S * T3_COND_ROWS * D, true))) return rc;
@@ -486,18 +488,19 @@ extern "C" int t3_step(T3Handle e, T3StepResult* res) {
     for (int L = 0; L < e->cfg.n_layers; ++L) {
         LayerW& y = e->layers[L];
         uint16_t* kvL = e->kv + (size_t)L * layer_elems;
-        { Prof p(e, K_NORM); HIP_TRY(launch_rmsnorm(e->h, y.ln1, e->xn, M, nullptr, s)); }
-        { Prof p(e, K_QKV); GemmArgs g{e->xn, (const uint4*)y.qkv, M, D, QKV, e->qkv, QKV}; HIP_TRY(launch_gemm(g, EPI_BF16, choose_mt(M, QKV / 16), s)); }
+        // previous layer's down_proj slabs are folded into the residual stream here
+        { Prof p(e, K_NORM); HIP_TRY(launch_add_rmsnorm(e->h, L ? e->part : nullptr, M, y.ln1, e->xn, M, nullptr, s)); }
+        { Prof p(e, K_QKV); GemmArgs g{e->xn, (const uint4*)y.qkv, M, D, QKV, e->qkv, QKV, 1}; HIP_TRY(launch_gemm(g, EPI_BF16, choose_mt(M, QKV / 16), s)); }
         { Prof p(e, K_ROPE); RopeArgs ra{e->qkv, e->qrot, kvL, e->dm.row_stream, e->dm.row_pos, e->d_block_table, e->max_blocks, e->cos_t, e->sin_t, M}; HIP_TRY(launch_rope_kv(ra, s)); }
         { Prof p(e, K_ATTN); AttnArgs aa{e->qrot, kvL, e->dm.row_stream, e->dm.row_pos, e->d_block_table, e->max_blocks, e->att, M, e->max_blocks}; HIP_TRY(launch_attention(aa, s)); }
-        { Prof p(e, K_O); GemmArgs g{e->att, (const uint4*)y.o, M, D, D, e->h, D}; HIP_TRY(launch_gemm(g, EPI_RESID, choose_mt(M, D / 16), s)); }
-        { Prof p(e, K_NORM); HIP_TRY(launch_rmsnorm(e->h, y.ln2, e->xn, M, nullptr, s)); }
-        { Prof p(e, K_GU); GemmArgs g{e->xn, (const uint4*)y.gu, M, D, F, e->act, F}; HIP_TRY(launch_gemm(g, EPI_SILU, choose_mt(M, F / 16), s)); }
-        { Prof p(e, K_DOWN); GemmArgs g{e->act, (const uint4*)y.down, M, F, D, e->h, D}; HIP_TRY(launch_gemm(g, EPI_RESID, choose_mt(M, D / 16), s)); }
+        { Prof p(e, K_O); GemmArgs g{e->att, (const uint4*)y.o, M, D, D, e->part, D, 4}; HIP_TRY(launch_gemm(g, EPI_F32, choose_mt(M, D / 16), s)); }
+        { Prof p(e, K_NORM); HIP_TRY(launch_add_rmsnorm(e->h, e->part, M, y.ln2, e->xn, M, nullptr, s)); }
+        { Prof p(e, K_GU); GemmArgs g{e->xn, (const uint4*)y.gu, M, D, F, e->act, F, 1}; HIP_TRY(launch_gemm(g, EPI_SILU, choose_mt(M, F / 16), s)); }
+        { Prof p(e, K_DOWN); GemmArgs g{e->act, (const uint4*)y.down, M, F, D, e->part, D, 4}; HIP_TRY(launch_gemm(g, EPI_F32, choose_mt(M, D / 16), s)); }
     }
     if (n_sel > 0) {
-        { Prof p(e, K_NORM); HIP_TRY(launch_rmsnorm(e->h, e->norm, e->xlast, 2 * n_sel, e->dm.sel_rows, s)); }
-        { Prof p(e, K_HEAD); GemmArgs g{e->xlast, (const uint4*)e->head, 2 * n_sel, D, V, e->logits, VPAD}; HIP_TRY(launch_gemm(g, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16), s)); }
+        { Prof p(e, K_NORM); HIP_TRY(launch_add_rmsnorm(e->h, e->part, M, e->norm, e->xlast, 2 * n_sel, e->dm.sel_rows, s)); }
+        { Prof p(e, K_HEAD); GemmArgs g{e->xlast, (const uint4*)e->head, 2 * n_sel, D, V, e->logits, VPAD, 1}; HIP_TRY(launch_gemm(g, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16), s)); }
         { Prof p(e, K_SAMPLE); SampleArgs sa{e->logits, VPAD, e->dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, e->dm.out_tok, e->d_dbg, n_sel}; HIP_TRY(launch_sampler(sa, s)); }
         HIP_TRY(hipMemcpyAsync(e->h_out_tok, e->dm.out_tok, (size_t)n_sel * 4, hipMemcpyDeviceToHost, s));
     }

@@ -32,18 +32,28 @@ bool have_device() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n 
 
 #define K_TRY(expr) do { if ((expr) != hipSuccess) return T3_E_DEVICE; } while (0)
 
-extern "C" int t3k_gemm(const void* x, const void* w, int32_t M, int32_t K, int32_t N, float* out, int32_t mt) {
-    if (!x || !w || !out || M <= 0 || N <= 0 || K % 128) return T3_E_INVALID;
+extern "C" int t3k_gemm(const void* x, const void* w, int32_t M, int32_t K, int32_t N, float* out, int32_t mt, int32_t ksplit) {
+    if (!x || !w || !out || M <= 0 || N <= 0 || (ksplit != 1 && ksplit != 4) || K % (128 * ksplit)) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
     const int Npad = (N + 15) / 16 * 16;
     std::vector<uint16_t> packed((size_t)Npad * K);
     pack_weight((const uint16_t*)w, N, K, Npad, packed.data());
     DevBuf dx, dw, dout;
-    K_TRY(dx.from(x, (size_t)M * K * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * N * 4, true));
-    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, K, N, dout.p, N};
+    K_TRY(dx.from(x, (size_t)M * K * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)ksplit * M * N * 4, true));
+    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, K, N, dout.p, N, ksplit};
     K_TRY(launch_gemm(a, EPI_F32, mt > 0 ? mt : choose_mt(M, Npad / 16), nullptr));
     K_TRY(hipDeviceSynchronize());
-    K_TRY(hipMemcpy(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    if (ksplit == 1) { K_TRY(hipMemcpy(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost)); return T3_OK; }
+    // fold the four slabs the way add_rmsnorm_kernel does: ((G0 + G1) + G2) + G3
+    std::vector<float> slabs((size_t)4 * M * N);
+    K_TRY(hipMemcpy(slabs.data(), dout.p, slabs.size() * 4, hipMemcpyDeviceToHost));
+    const size_t sl = (size_t)M * N;
+    for (size_t i = 0; i < sl; ++i) {
+        volatile float t = slabs[i] + slabs[sl + i];
+        t = t + slabs[2 * sl + i];
+        t = t + slabs[3 * sl + i];
+        out[i] = t;
+    }
     return T3_OK;
 }
 
@@ -52,9 +62,22 @@ extern "C" int t3k_rmsnorm(const void* x, const void* w, void* y, int32_t rows) 
     if (!have_device()) return T3_E_DEVICE;
     DevBuf dx, dw, dy;
     K_TRY(dx.from(x, (size_t)rows * D * 2)); K_TRY(dw.from(w, D * 2)); K_TRY(dy.alloc((size_t)rows * D * 2));
-    K_TRY(launch_rmsnorm(dx.as<uint16_t>(), dw.as<uint16_t>(), dy.as<uint16_t>(), rows, nullptr, nullptr));
+    K_TRY(launch_add_rmsnorm(dx.as<uint16_t>(), nullptr, rows, dw.as<uint16_t>(), dy.as<uint16_t>(), rows, nullptr, nullptr));
     K_TRY(hipDeviceSynchronize());
     K_TRY(hipMemcpy(y, dy.p, (size_t)rows * D * 2, hipMemcpyDeviceToHost));
+    return T3_OK;
+}
+
+/* h [rows][1024] bf16 (updated), P [4][rows][1024] fp32, w [1024] -> y = RMSNorm(h + bf16(fold(P))) * w */
+extern "C" int t3k_add_rmsnorm(void* h, const float* P, const void* w, void* y, int32_t rows) {
+    if (!h || !P || !w || !y || rows <= 0) return T3_E_INVALID;
+    if (!have_device()) return T3_E_DEVICE;
+    DevBuf dh, dp, dw, dy;
+    K_TRY(dh.from(h, (size_t)rows * D * 2)); K_TRY(dp.from(P, (size_t)4 * rows * D * 4)); K_TRY(dw.from(w, D * 2)); K_TRY(dy.alloc((size_t)rows * D * 2));
+    K_TRY(launch_add_rmsnorm(dh.as<uint16_t>(), dp.as<float>(), rows, dw.as<uint16_t>(), dy.as<uint16_t>(), rows, nullptr, nullptr));
+    K_TRY(hipDeviceSynchronize());
+    K_TRY(hipMemcpy(y, dy.p, (size_t)rows * D * 2, hipMemcpyDeviceToHost));
+    K_TRY(hipMemcpy(h, dh.p, (size_t)rows * D * 2, hipMemcpyDeviceToHost));
     return T3_OK;
 }
 
@@ -65,7 +88,7 @@ extern "C" int t3k_silu_mul_gemm(const void* x, const void* wg, const void* wu, 
     pack_gate_up((const uint16_t*)wg, (const uint16_t*)wu, Fd, D, packed.data());
     DevBuf dx, dw, dout;
     K_TRY(dx.from(x, (size_t)M * D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * Fd * 2, true));
-    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, D, Fd, dout.p, Fd};
+    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, D, Fd, dout.p, Fd, 1};
     K_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, Fd / 16), nullptr));
     K_TRY(hipDeviceSynchronize());
     K_TRY(hipMemcpy(out, dout.p, (size_t)M * Fd * 2, hipMemcpyDeviceToHost));

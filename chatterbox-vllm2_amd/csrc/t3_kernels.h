@@ -19,6 +19,7 @@ struct GemmArgs {
     int M, K, N;         // N = number of valid output columns (EPI_SILU: F)
     void* out;           // EPI_F32: float [M][ldo]; else bf16 [M][ldo]; EPI_RESID: residual stream, updated in place
     int ldo;
+    int ksplit;          // 1, or 4: four workgroups per tile each write an fp32 partial slab [ksplit][M][ldo] (EPI_F32 only)
 };
 
 // Host-side packing of a [N][K] bf16 matrix into MFMA-B-operand order:
@@ -29,7 +30,8 @@ void pack_gate_up(const uint16_t* Wg, const uint16_t* Wu, int Fdim, int K, uint1
 
 int choose_mt(int M, int ntiles_x);
 hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s);
-hipError_t launch_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, const int* gather, hipStream_t s);
+// P (nullable): four fp32 slabs [4][Mrows][1024] of a ksplit=4 GEMM, folded and added to h (in place unless gather) before the norm
+hipError_t launch_add_rmsnorm(uint16_t* h, const float* P, int Mrows, const uint16_t* w, uint16_t* y, int rows, const int* gather, hipStream_t s);
 
 struct EmbedArgs {
     const int4* desc;          // per row {kind, a, b, c}

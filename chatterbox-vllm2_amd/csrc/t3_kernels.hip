@@ -77,7 +77,9 @@ __device__ __forceinline__ uint32_t silu_mul_bf(uint32_t g, uint32_t u) {   // b
 // Contract order (DESIGN.md "GEMM"): K is cut into 4 contiguous segments (one per wave of the
 // workgroup); a wave folds its segment with a chain of v_mfma_f32_16x16x32_bf16 in ascending k (each
 // instruction folds 4 blocks of 8 consecutive k into the fp32 accumulator; its exact arithmetic was
-// identified on-device and is restated in the checker); result = ((p0 + p1) + p2) + p3 in fp32.
+// identified on-device and is restated in the checker); the workgroup's result is the group sum
+// G = ((s0 + s1) + s2) + s3 in fp32.  With ksplit = 4 (o_proj, down_proj) four workgroups (blockIdx.z) each
+// write their G as an fp32 slab and the consumer (add_rmsnorm_kernel) folds ((G0 + G1) + G2) + G3.
 //
 // One workgroup = 4 waves = NT n-tiles of 16 columns x MT m-tiles of 16 rows.  Weights are packed so
 // that a wave's weight load is one contiguous 1 KiB (pack_weight); activations are read row-major,
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][MT*NT][4 regs][64 lanes]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int KB = a.K >> 5, kbs = KB >> 2, kb0 = wave * kbs;
+    const int KB = a.K >> 5, kbs = (KB >> 2) / (int)gridDim.z, kb0 = ((int)blockIdx.z * 4 + wave) * kbs;
 
     const uint4* wp[NT];
     const uint4* xp[MT];
@@ -177,8 +179,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
             for (int t = 0; t < NT; ++t) {
                 const int n = (blockIdx.x * NT + t) * 16 + ncol;
                 if (n >= a.N) continue;
-                if constexpr (EPI == EPI_F32) {
-                    reinterpret_cast<float*>(a.out)[(size_t)m * a.ldo + n] = v[t];
+                if constexpr (EPI == EPI_F32) {     // blockIdx.z > 0: partial slab z of a split-K launch
+                    reinterpret_cast<float*>(a.out)[((size_t)blockIdx.z * a.M + m) * a.ldo + n] = v[t];
                 } else if constexpr (EPI == EPI_BF16) {
                     reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)f2bf(v[t]);
                 } else {   // EPI_RESID: h = bf16(h + bf16(y))
@@ -208,13 +210,14 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     const int gx = (EPI == EPI_SILU) ? ntiles : (ntiles + NT - 1) / NT;
     const int gy = ((a.M + 15) / 16 + MT - 1) / MT;
     const size_t lds = (size_t)4 * MT * NT * 4 * 64 * sizeof(float);
-    hipLaunchKernelGGL((gemm_kernel<MT, NT, EPI, PD>), dim3(gx, gy), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_kernel<MT, NT, EPI, PD>), dim3(gx, gy, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
-    if (a.K % 128 != 0) return hipErrorInvalidValue;
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    if (a.K % (128 * ks) != 0 || (ks > 1 && epi != EPI_F32)) return hipErrorInvalidValue;
 #define T3_CASE(E, NT)                                                   \
     switch (mt) {                                                        \
         case 1: return launch_gemm_t<1, NT, E>(a, s);                    \
@@ -252,19 +255,50 @@ void pack_gate_up(const uint16_t* Wg, const uint16_t* Wu, int Fdim, int K, uint1
 }
 
 // ------------------------------------------------------------------------------------------------
-// RMSNorm: one wave per row of 1024.  Contract: lane l owns elements 8l..8l+7 then 512+8l..;
-// sequential x*x adds; butterfly add over xor 32,16,8,4,2,1; rstd = 1/sqrt(ss/1024 + eps);
-// y = bf16(bf16(x*rstd) * w).  gather (optional): input row index per output row.
+// (split-K fold + residual add +) RMSNorm: one wave per row of 1024.
+//   if P != null:  d = ((P0 + P1) + P2) + P3  (the four fp32 slabs of a ksplit=4 GEMM);  h = bf16(h + bf16(d))
+//   y = RMSNorm(h) * w
+// RMSNorm contract: lane l owns elements 8l..8l+7 then 512+8l..; sequential x*x adds; butterfly add over
+// xor 32,16,8,4,2,1; rstd = 1/sqrt(ss/1024 + eps); y = bf16(bf16(x*rstd) * w).
+// gather (optional): source row index per output row (h is then left untouched: the head only needs y).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
-                                                      uint16_t* __restrict__ y, int rows, const int* __restrict__ gather) {
+__device__ __forceinline__ void fold4(const float* P, size_t slab, size_t off, float* d) {
+    const float4* p0 = reinterpret_cast<const float4*>(P + off);
+    const float4* p1 = reinterpret_cast<const float4*>(P + slab + off);
+    const float4* p2 = reinterpret_cast<const float4*>(P + 2 * slab + off);
+    const float4* p3 = reinterpret_cast<const float4*>(P + 3 * slab + off);
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+        const float4 a = p0[hlf], b = p1[hlf], c = p2[hlf], e = p3[hlf];
+        d[4 * hlf + 0] = ((a.x + b.x) + c.x) + e.x; d[4 * hlf + 1] = ((a.y + b.y) + c.y) + e.y;
+        d[4 * hlf + 2] = ((a.z + b.z) + c.z) + e.z; d[4 * hlf + 3] = ((a.w + b.w) + c.w) + e.w;
+    }
+}
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(uint16_t* __restrict__ h, const float* __restrict__ P, int Mrows,
+                                                          const uint16_t* __restrict__ w, uint16_t* __restrict__ y, int rows,
+                                                          const int* __restrict__ gather) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int src = gather ? gather[row] : row;
-    const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)src * D);
-    const uint4 va = xr[lane], vb = xr[64 + lane];
+    uint4* xr = reinterpret_cast<uint4*>(h + (size_t)src * D);
+    const uint4* wr = reinterpret_cast<const uint4*>(w);
+    const uint4 va = xr[lane], vb = xr[64 + lane], wva = wr[lane], wvb = wr[64 + lane];
     float fa[8], fb[8];
     unpack8(va, fa); unpack8(vb, fb);
+    if (P) {
+        float da[8], db[8];
+        const size_t slab = (size_t)Mrows * D;
+        fold4(P, slab, (size_t)src * D + 8 * lane, da);
+        fold4(P, slab, (size_t)src * D + 512 + 8 * lane, db);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { fa[e] = rbf(fa[e] + rbf(da[e])); fb[e] = rbf(fb[e] + rbf(db[e])); }
+        if (!gather) {
+            uint4 na, nb;
+            na.x = pack2(fa[0], fa[1]); na.y = pack2(fa[2], fa[3]); na.z = pack2(fa[4], fa[5]); na.w = pack2(fa[6], fa[7]);
+            nb.x = pack2(fb[0], fb[1]); nb.y = pack2(fb[2], fb[3]); nb.z = pack2(fb[4], fb[5]); nb.w = pack2(fb[6], fb[7]);
+            xr[lane] = na; xr[64 + lane] = nb;
+        }
+    }
     float ss = 0.0f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(fa[e], fa[e], ss);
@@ -273,9 +307,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) ss = ss + __shfl_xor(ss, off);
     const float rstd = 1.0f / sqrtf(ss * (1.0f / 1024.0f) + 1e-5f);
-    const uint4* wr = reinterpret_cast<const uint4*>(w);
     float wa[8], wb[8];
-    unpack8(wr[lane], wa); unpack8(wr[64 + lane], wb);
+    unpack8(wva, wa); unpack8(wvb, wb);
     uint4 oa, ob;
     oa.x = pack2(rbf(fa[0] * rstd) * wa[0], rbf(fa[1] * rstd) * wa[1]);
     oa.y = pack2(rbf(fa[2] * rstd) * wa[2], rbf(fa[3] * rstd) * wa[3]);
@@ -289,9 +322,9 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict
     yr[lane] = oa; yr[64 + lane] = ob;
 }
 
-hipError_t launch_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, const int* gather, hipStream_t s) {
+hipError_t launch_add_rmsnorm(uint16_t* h, const float* P, int Mrows, const uint16_t* w, uint16_t* y, int rows, const int* gather, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, y, rows, gather);
+    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, P, Mrows, w, y, rows, gather);
     return hipGetLastError();
 }
 

@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "t3_create", "t3_destroy", "t3_last_error", "t3_load_tensor", "t3_finalize_weights", "t3_add_request",
     "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_release_request",
     "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_kernel_ms",
-    "t3k_gemm", "t3k_rmsnorm", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_sample", "t3k_expf",
+    "t3k_gemm", "t3k_rmsnorm", "t3k_add_rmsnorm", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_sample", "t3k_expf",
 ]
 
 KERNEL_CLASSES = ["gemm_qkv", "gemm_o", "gemm_gateup", "gemm_down", "gemm_head", "attention", "rmsnorm",
@@ -106,7 +106,8 @@ def load_library():
     L.t3_reset_stats.argtypes = [vp]
     L.t3_set_profile.argtypes = [vp, i32]
     L.t3_kernel_ms.argtypes = [vp, ct.c_char_p, ct.POINTER(ct.c_double), ct.POINTER(i64)]
-    L.t3k_gemm.argtypes = [vp, vp, i32, i32, i32, vp, i32]
+    L.t3k_gemm.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32]
+    L.t3k_add_rmsnorm.argtypes = [vp, vp, vp, vp, i32]
     L.t3k_rmsnorm.argtypes = [vp, vp, vp, i32]
     L.t3k_silu_mul_gemm.argtypes = [vp, vp, vp, i32, i32, vp]
     L.t3k_rope_attention.argtypes = [vp, vp, vp, i32, i32, i32, vp]
@@ -262,12 +263,21 @@ def _bf(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
-def k_gemm(x: torch.Tensor, W: torch.Tensor, mt: int = 0) -> torch.Tensor:
+def k_gemm(x: torch.Tensor, W: torch.Tensor, mt: int = 0, ksplit: int = 1) -> torch.Tensor:
+    """ksplit=1: four K-segments in one workgroup; ksplit=4: sixteen segments over four workgroups (o_proj/down_proj form)."""
     x, W = _bf(x), _bf(W)
     M, K = x.shape; N = W.shape[0]
     out = torch.empty(M, N, dtype=torch.float32)
-    _chk_k(load_library().t3k_gemm(x.data_ptr(), W.data_ptr(), M, K, N, out.data_ptr(), mt), "t3k_gemm")
+    _chk_k(load_library().t3k_gemm(x.data_ptr(), W.data_ptr(), M, K, N, out.data_ptr(), mt, ksplit), "t3k_gemm")
     return out
+
+
+def k_add_rmsnorm(h: torch.Tensor, P: torch.Tensor, w: torch.Tensor):
+    """h [rows,1024] bf16, P [4,rows,1024] fp32 -> (h_new, y)"""
+    h = _bf(h).clone(); w = _bf(w); P = P.to(torch.float32).contiguous()
+    y = torch.empty_like(h)
+    _chk_k(load_library().t3k_add_rmsnorm(h.data_ptr(), P.data_ptr(), w.data_ptr(), y.data_ptr(), h.shape[0]), "t3k_add_rmsnorm")
+    return h, y
 
 
 def k_rmsnorm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:

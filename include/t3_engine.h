@@ -140,8 +140,10 @@ int t3_kernel_ms(T3Handle h, const char* name, double* avg_ms, int64_t* launches
 /* ---- kernel-level entry points (host buffers in, host buffers out; used by the parity tests) ----
  * Each runs exactly the kernel the engine uses, on the current device, and waits for it.      */
 int t3k_gemm(const void* x_bf16 /*[M][K]*/, const void* w_bf16 /*[N][K]*/, int32_t M, int32_t K, int32_t N,
-             float* out_f32 /*[M][N]*/, int32_t mt /*0 = auto*/);
+             float* out_f32 /*[M][N]*/, int32_t mt /*0 = auto*/, int32_t ksplit /*1, or 4 = o_proj/down_proj form*/);
 int t3k_rmsnorm(const void* x_bf16, const void* w_bf16, void* y_bf16, int32_t rows);
+/* split-K fold + residual add + RMSNorm: h [rows][1024] bf16 (updated in place), P [4][rows][1024] fp32 slabs */
+int t3k_add_rmsnorm(void* h_bf16, const float* P_f32, const void* w_bf16, void* y_bf16, int32_t rows);
 int t3k_silu_mul_gemm(const void* x_bf16 /*[M][1024]*/, const void* wg_bf16 /*[F][1024]*/, const void* wu_bf16,
                       int32_t M, int32_t F, void* out_bf16 /*[M][F]*/);
 /* RoPE + paged-KV write + paged attention for `rows` rows of ONE layer over a scratch pool:

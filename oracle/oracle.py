@@ -56,7 +56,7 @@ def lib():
         L = ct.CDLL(_SO)
         vp, i32, f32 = ct.c_void_p, ct.c_int, ct.c_float
         L.orc_expf.restype = f32; L.orc_expf.argtypes = [f32]
-        L.orc_gemm_nk.argtypes = [vp, vp, i32, i32, i32, vp]
+        L.orc_gemm_nk.argtypes = [vp, vp, i32, i32, i32, vp, i32]
         L.orc_rmsnorm.argtypes = [vp, vp, vp, i32]
         L.orc_rope_table.argtypes = [i32, vp, vp]
         L.orc_rope.argtypes = [vp, vp, i32, vp, vp]
@@ -91,12 +91,15 @@ def expf(x: float) -> float:
     return float(lib().orc_expf(ct.c_float(x)))
 
 
-def gemm(x: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
-    """x [M,K] bf16, W [N,K] bf16 -> [M,N] fp32 in the contract summation order."""
+def gemm(x: torch.Tensor, W: torch.Tensor, seg_len: int = 0) -> torch.Tensor:
+    """x [M,K] bf16, W [N,K] bf16 -> [M,N] fp32 in the contract summation order.
+    seg_len: MFMA chain length per segment (K/seg_len must be 4 or 16); default K/4."""
     x, W = _bf(x), _bf(W)
     M, K = x.shape; N = W.shape[0]
+    seg_len = seg_len or K // 4
+    assert K % seg_len == 0 and K // seg_len in (4, 16) and seg_len % 32 == 0
     out = torch.empty(M, N, dtype=torch.float32)
-    lib().orc_gemm_nk(_p(x), _p(W), M, K, N, _p(out))
+    lib().orc_gemm_nk(_p(x), _p(W), M, K, N, _p(out), seg_len)
     return out
 
 

@@ -42,6 +42,24 @@ def test_gemm_bit_exact(E, oracle, M, K, N, mt):
     assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,K,N,mt", [(64, 1024, 1024, 0), (64, 4096, 1024, 0), (3, 4096, 48, 1), (130, 1024, 64, 8), (16, 512, 32, 0)])
+def test_gemm_split4_bit_exact(E, oracle, M, K, N, mt):
+    """o_proj / down_proj form: 16 segments of K/16 over four workgroups, slabs folded ((G0+G1)+G2)+G3."""
+    x = rand_bf16(M, K, seed=M + K + 1); W = rand_bf16(N, K, seed=N + 1, scale=0.05)
+    assert_bit_equal(E.k_gemm(x, W, mt, ksplit=4), oracle.gemm(x, W, K // 16), f"split-K gemm {M}x{K}x{N}")
+
+
+def test_add_rmsnorm_bit_exact(E, oracle):
+    rows = 37
+    h = rand_bf16(rows, 1024, seed=1, scale=2.0); w = (rand_bf16(1024, seed=2) + 1.0).to(torch.bfloat16)
+    P = torch.randn(4, rows, 1024, generator=torch.Generator().manual_seed(3))
+    d = (((P[0] + P[1]) + P[2]) + P[3]).to(torch.bfloat16)
+    want_h = (h.float() + d.float()).to(torch.bfloat16)
+    got_h, got_y = E.k_add_rmsnorm(h, P, w)
+    assert_bit_equal(got_h, want_h, "residual add")
+    assert_bit_equal(got_y, oracle.rmsnorm(want_h, w), "rmsnorm after add")
+
+
 def test_gemm_wide_dynamic_range(E, oracle):
     g = torch.Generator().manual_seed(5)
     x = (torch.randn(32, 1024, generator=g) * torch.exp2(torch.randint(-12, 12, (32, 1024), generator=g).float())).to(torch.bfloat16)
