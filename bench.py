@@ -87,8 +87,9 @@ def run_pass(eng, reqs, cond, warmup, steps, sync, profile=False):
 def cpu_baseline(weights, args):
     """The oracle (a port, kind="port") timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import oracle as O
-    ncores = os.cpu_count() or 1
-    B, ctx, steps = args.batch, 500, 4
+    ncores = int(os.environ.get("T3_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))   # the box grants a 16-core share
+    O.set_threads(ncores)
+    B, ctx, steps = args.batch, 500, 2
     m = O.OracleModel(args.layers, 2454, max_pos=ctx + steps + 2, n_streams=2 * B).load(weights)
     m.decode_steps_timing(1, ctx, 1)                     # touch the weights once
     t0 = time.perf_counter()

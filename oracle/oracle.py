@@ -49,6 +49,16 @@ def make_sampling(temperature=0.8, top_p=1.0, min_p=0.0, repetition_penalty=2.0,
 _lib = None
 
 
+def set_threads(n: int) -> int:
+    """OpenMP thread count of the oracle's parallel loops (the GPU box reports 256 CPUs but grants a 16-core share)."""
+    import ctypes.util
+    try:
+        ct.CDLL(ctypes.util.find_library("gomp") or "libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        os.environ["OMP_NUM_THREADS"] = str(n)
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
