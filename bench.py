@@ -136,7 +136,7 @@ def main():
     weights = list(synthetic_tensors(args.layers, 2454, 1234))
     cond = synthetic_cond_emb(1)
     eng = E.T3Engine(n_layers=args.layers, text_vocab=2454, max_model_len=args.max_model_len, max_seqs=args.batch,
-                     device_id=local_rank, gpu_memory_utilization=0.5, max_batched_rows=8192)
+                     device_id=local_rank, gpu_memory_utilization=0.5, max_batched_rows=8192, enforce_eager=bool(int(os.environ.get('T3_EAGER', '0'))))
     eng.load_tensors(weights); eng.finalize()
     reqs = build_requests(E, args, rank)
 

@@ -23,5 +23,6 @@ N_LAYERS = 30                    # config.json:17
 RMS_EPS = 1e-5                   # config.json:20
 S3_TOKEN_RATE = 25               # models/s3tokenizer/s3tokenizer.py:18 (speech tokens per second)
 
-KV_BLOCK_TOKENS = 64             # engine KV block == attention chunk
+ATTN_CHUNK_TOKENS = 64           # attention chunk (numerics contract)
+KV_BLOCK_TOKENS = 256            # physical KV block: 4 chunks, 32 KiB K + 32 KiB V contiguous per head
 KV_BYTES_PER_TOKEN_PER_STREAM = 2 * N_LAYERS * N_HEADS * HEAD_DIM * 2   # 122 880

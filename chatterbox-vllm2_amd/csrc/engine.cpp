@@ -8,6 +8,7 @@
 // split_prefill_decode (t3.py:340-421) has no equivalent here: the scheduler knows which rows are
 // prefill and which are decode.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,11 +59,14 @@ static const char* kclass_names[K_COUNT] = {"gemm_qkv", "gemm_o", "gemm_gateup",
 struct T3Engine {
     T3EngineConfig cfg{};
     std::string err;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // admission copies (cond, sampling params, block table); groups wait on ev_admit
+    hipEvent_t ev_admit = nullptr;
     bool finalized = false;
     int max_blocks = 0;        // per stream
     int64_t n_blocks = 0;      // pool
-    int rmax = 0;              // row budget per step
+    int rmax = 0;              // row budget per step (all groups)
+    int n_groups = 1;
+    bool fuse_rope = true;
 
     // weights (device)
     std::vector<LayerW> layers;
@@ -77,20 +81,29 @@ struct T3Engine {
     int* d_block_table = nullptr;
     std::vector<int> h_block_table;
 
-    // activations
-    uint16_t *h = nullptr, *xn = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *act = nullptr, *xlast = nullptr, *logits = nullptr;
-    float* part = nullptr;     // [4][rmax][1024] fp32 split-K slabs of o_proj / down_proj
+    // utterance groups: each group owns a stream, activation buffers, step metadata and captured graphs, so that
+    // one group's HBM-bound attention overlaps another group's latency-bound GEMM chain on the same GPU
+    struct Meta { int* row_stream; int* row_pos; int4* desc; int* sel_rows; int4* sel; int* out_tok; };
+    struct Group {
+        hipStream_t stream = nullptr;
+        uint16_t *h = nullptr, *xn = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *act = nullptr, *xlast = nullptr, *logits = nullptr;
+        float* part = nullptr;     // [4][rcap][1024] fp32 split-K slabs of o_proj / down_proj
+        char *h_meta = nullptr, *d_meta = nullptr;
+        size_t meta_bytes = 0;
+        Meta hm{}, dm{};
+        int* h_out_tok = nullptr;
+        int rcap = 0;              // row budget per step
+        std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (M, n_sel) -> captured decode step
+        // per-step scratch
+        int M = 0, n_sel = 0, n_prefill_rows = 0, decode_rows = 0;
+        double sum_ctx = 0;
+        std::vector<Request*> sampled;
+    };
+    std::vector<Group> groups;
     float* d_cond = nullptr;
     uint16_t* d_counts = nullptr;
     T3Sampling* d_sp = nullptr;
     float* d_dbg = nullptr;
-
-    // per-step metadata: one pinned host block mirrored by one device block
-    struct Meta { int* row_stream; int* row_pos; int4* desc; int* sel_rows; int4* sel; int* out_tok; };
-    char *h_meta = nullptr, *d_meta = nullptr;
-    size_t meta_bytes = 0;
-    Meta hm{}, dm{};
-    int* h_out_tok = nullptr;
 
     // scheduler
     std::unordered_map<int64_t, Request> reqs;
@@ -139,11 +152,21 @@ extern "C" int t3_create(const T3EngineConfig* cfg, T3Handle* out) {
     e->rmax = cfg->max_batched_rows > 0 ? cfg->max_batched_rows : std::max(2048, 2 * cfg->max_seqs);
     e->rmax = std::max(e->rmax, 2 * cfg->max_seqs);
     e->slot_req.assign(cfg->max_seqs, -1);
+    {
+        int g = cfg->n_groups > 0 ? cfg->n_groups : 1;   // measured on MI355X/ROCm 7.2: kernels of different streams do not overlap usefully (2 groups +0 %, 4 groups -60 %)
+        if (const char* ev = getenv("T3_GROUPS")) g = atoi(ev);
+        e->n_groups = std::max(1, std::min(g, std::min(8, cfg->max_seqs)));
+        e->groups.resize(e->n_groups);
+        if (const char* ev = getenv("T3_FUSE_ROPE")) e->fuse_rope = atoi(ev) != 0;
+    }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail_create(T3_E_DEVICE, "hipStreamCreate failed"); }
-    hipEventCreate(&e->ev0); hipEventCreate(&e->ev1);
+    hipEventCreate(&e->ev0); hipEventCreate(&e->ev1); hipEventCreateWithFlags(&e->ev_admit, hipEventDisableTiming);
+    for (auto& g : e->groups)
+        if (hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail_create(T3_E_DEVICE, "hipStreamCreate failed"); }
     *out = e;
     return T3_OK;
 }
+
 
 static void free_dev(void* p) { if (p) (void)hipFree(p); }
 
@@ -154,10 +177,17 @@ extern "C" int t3_destroy(T3Handle e) {
     for (auto& L : e->layers) { free_dev(L.qkv); free_dev(L.o); free_dev(L.gu); free_dev(L.down); free_dev(L.ln1); free_dev(L.ln2); }
     free_dev(e->norm); free_dev(e->text_emb); free_dev(e->speech_emb); free_dev(e->text_pos); free_dev(e->speech_pos); free_dev(e->head);
     free_dev(e->cos_t); free_dev(e->sin_t); free_dev(e->kv); free_dev(e->d_block_table);
-    free_dev(e->h); free_dev(e->xn); free_dev(e->qkv); free_dev(e->qrot); free_dev(e->att); free_dev(e->act); free_dev(e->xlast); free_dev(e->logits);
-    free_dev(e->part); free_dev(e->d_cond); free_dev(e->d_counts); free_dev(e->d_sp); free_dev(e->d_dbg); free_dev(e->d_meta);
-    if (e->h_meta) (void)hipHostFree(e->h_meta);
-    if (e->h_out_tok) (void)hipHostFree(e->h_out_tok);
+    for (auto& g : e->groups) {
+        if (g.stream) (void)hipStreamSynchronize(g.stream);
+        for (auto& kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
+        free_dev(g.h); free_dev(g.xn); free_dev(g.qkv); free_dev(g.qrot); free_dev(g.att); free_dev(g.act); free_dev(g.xlast); free_dev(g.logits);
+        free_dev(g.part); free_dev(g.d_meta); free_dev(g.dm.out_tok);
+        if (g.h_meta) (void)hipHostFree(g.h_meta);
+        if (g.h_out_tok) (void)hipHostFree(g.h_out_tok);
+        if (g.stream) (void)hipStreamDestroy(g.stream);
+    }
+    free_dev(e->d_cond); free_dev(e->d_counts); free_dev(e->d_sp); free_dev(e->d_dbg);
+    if (e->ev_admit) (void)hipEventDestroy(e->ev_admit);
     for (int k = 0; k < K_COUNT; ++k) for (auto& p : e->pev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -292,41 +322,44 @@ extern "C" int t3_finalize_weights(T3Handle e) {
         HIP_TRY(hipMemcpy(e->cos_t, c.data(), c.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(e->sin_t, s.data(), s.size() * 4, hipMemcpyHostToDevice));
     }
-    // activations
-    const size_t R = (size_t)e->rmax, S = (size_t)e->cfg.max_seqs;
-    if ((rc = dalloc(e, &e->h, R * D, true))) return rc;
-    if ((rc = dalloc(e, &e->xn, R * D, true))) return rc;
-    if ((rc = dalloc(e, &e->qkv, R * QKV, true))) return rc;
-    if ((rc = dalloc(e, &e->qrot, R * D, true))) return rc;
-    if ((rc = dalloc(e, &e->att, R * D, true))) return rc;
-    if ((rc = dalloc(e, &e->act, R * F, true))) return rc;
-    if ((rc = dalloc(e, &e->part, 4 * R * D, true))) return rc;
-    if ((rc = dalloc(e, &e->xlast, 2 * S * D, true))) return rc;
-    if ((rc = dalloc(e, &e->logits, 2 * S * VPAD, true))) return rc;
+    // per-group activations + metadata
+    const size_t S = (size_t)e->cfg.max_seqs;
+    const size_t Sg = (S + e->n_groups - 1) / e->n_groups;          // utterance slots per group (slot % n_groups)
+    for (auto& g : e->groups) {
+        g.rcap = std::max((int)(2 * Sg), e->rmax / e->n_groups);
+        const size_t R = (size_t)g.rcap;
+        if ((rc = dalloc(e, &g.h, R * D, true))) return rc;
+        if ((rc = dalloc(e, &g.xn, R * D, true))) return rc;
+        if ((rc = dalloc(e, &g.qkv, R * QKV, true))) return rc;
+        if ((rc = dalloc(e, &g.qrot, R * D, true))) return rc;
+        if ((rc = dalloc(e, &g.att, R * D, true))) return rc;
+        if ((rc = dalloc(e, &g.act, R * F, true))) return rc;
+        if ((rc = dalloc(e, &g.part, 4 * R * D, true))) return rc;
+        if ((rc = dalloc(e, &g.xlast, 2 * Sg * D, true))) return rc;
+        if ((rc = dalloc(e, &g.logits, 2 * Sg * VPAD, true))) return rc;
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_rs = carve(R * 4), o_rp = carve(R * 4), o_desc = carve(R * 16), o_selr = carve(2 * Sg * 4), o_sel = carve(Sg * 16);
+        g.meta_bytes = off;
+        HIP_TRY(hipHostMalloc((void**)&g.h_meta, g.meta_bytes, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void**)&g.d_meta, g.meta_bytes));
+        auto fill = [&](T3Engine::Meta& m, char* base) {
+            m.row_stream = (int*)(base + o_rs); m.row_pos = (int*)(base + o_rp); m.desc = (int4*)(base + o_desc);
+            m.sel_rows = (int*)(base + o_selr); m.sel = (int4*)(base + o_sel); m.out_tok = nullptr;
+        };
+        fill(g.hm, g.h_meta); fill(g.dm, g.d_meta);
+        int* dtok = nullptr;
+        if ((rc = dalloc(e, &dtok, Sg, true))) return rc;
+        g.dm.out_tok = dtok;
+        HIP_TRY(hipHostMalloc((void**)&g.h_out_tok, Sg * 4, hipHostMallocDefault));
+    }
     if ((rc = dalloc(e, &e->d_cond, S * T3_COND_ROWS * D, true))) return rc;
     if ((rc = dalloc(e, &e->d_counts, S * VPAD, true))) return rc;
     if ((rc = dalloc(e, &e->d_sp, S, true))) return rc;
     if (e->cfg.debug_logits && (rc = dalloc(e, &e->d_dbg, S * V, true))) return rc;
     if ((rc = dalloc(e, &e->d_block_table, 2 * S * e->max_blocks, true))) return rc;
     e->h_block_table.assign(2 * S * e->max_blocks, 0);
-    // metadata block
-    {
-        size_t off = 0;
-        auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-        const size_t o_rs = carve(R * 4), o_rp = carve(R * 4), o_desc = carve(R * 16), o_selr = carve(2 * S * 4), o_sel = carve(S * 16);
-        e->meta_bytes = off;
-        HIP_TRY(hipHostMalloc((void**)&e->h_meta, e->meta_bytes, hipHostMallocDefault));
-        HIP_TRY(hipMalloc((void**)&e->d_meta, e->meta_bytes));
-        auto fill = [&](T3Engine::Meta& m, char* base) {
-            m.row_stream = (int*)(base + o_rs); m.row_pos = (int*)(base + o_rp); m.desc = (int4*)(base + o_desc);
-            m.sel_rows = (int*)(base + o_selr); m.sel = (int4*)(base + o_sel); m.out_tok = nullptr;
-        };
-        fill(e->hm, e->h_meta); fill(e->dm, e->d_meta);
-        int* dtok = nullptr;
-        if ((rc = dalloc(e, &dtok, S, true))) return rc;
-        e->dm.out_tok = dtok;
-        HIP_TRY(hipHostMalloc((void**)&e->h_out_tok, S * 4, hipHostMallocDefault));
-    }
+    HIP_TRY(t3::prepare_kernels());
     // KV pool
     {
         const size_t per_block = (size_t)e->cfg.n_layers * KV_BLOCK_ELEMS * 2;   // bytes
@@ -412,21 +445,62 @@ static int admit(T3Engine* e) {
     }
     if (table_dirty)
         HIP_TRY(hipMemcpyAsync(e->d_block_table, e->h_block_table.data(), e->h_block_table.size() * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipEventRecord(e->ev_admit, e->stream));
     e->st.kv_blocks_free = (int64_t)e->free_blocks.size();
     return T3_OK;
 }
 
 struct Prof {
     T3Engine* e; int k; bool on; hipEvent_t a, b;
-    Prof(T3Engine* e_, int k_) : e(e_), k(k_), on(e_->profile) {
+    hipStream_t st;
+    Prof(T3Engine* e_, int k_, hipStream_t st_) : e(e_), k(k_), on(e_->profile), st(st_) {
         if (!on) return;
         auto& v = e->pev[k]; size_t& u = e->pev_used[k];
         if (u == v.size()) { hipEvent_t x, y; hipEventCreate(&x); hipEventCreate(&y); v.emplace_back(x, y); }
         a = v[u].first; b = v[u].second; ++u;
-        hipEventRecord(a, e->stream);
+        hipEventRecord(a, st);
     }
-    ~Prof() { if (on) hipEventRecord(b, e->stream); }
+    ~Prof() { if (on) hipEventRecord(b, st); }
 };
+
+// One group's kernel sequence for one step (eager, or recorded into a hipGraph by the caller).
+static int launch_step(T3Engine* e, T3Engine::Group& g) {
+    hipStream_t s = g.stream;
+    const int M = g.M, n_sel = g.n_sel;
+    {
+        Prof p(e, K_EMBED, s);
+        EmbedArgs ea{g.dm.desc, e->d_cond, e->text_emb, e->text_pos, e->speech_emb, e->speech_pos, g.h, M};
+        HIP_TRY(launch_embed(ea, s));
+    }
+    const size_t layer_elems = (size_t)e->n_blocks * KV_BLOCK_ELEMS;
+    for (int L = 0; L < e->cfg.n_layers; ++L) {
+        LayerW& y = e->layers[L];
+        uint16_t* kvL = e->kv + (size_t)L * layer_elems;
+        // previous layer's down_proj slabs are folded into the residual stream here
+        { Prof p(e, K_NORM, s); HIP_TRY(launch_add_rmsnorm(g.h, L ? g.part : nullptr, M, y.ln1, g.xn, M, nullptr, s)); }
+        { Prof p(e, K_QKV, s); GemmArgs a{g.xn, (const uint4*)y.qkv, M, D, QKV, g.qkv, QKV, 1}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16), s)); }
+        const int max_chunks = (e->cfg.max_model_len + CHUNK - 1) / CHUNK;
+        if (g.n_prefill_rows == 0 && e->fuse_rope) {
+            // decode-only step: every row is the newest position of its stream -> RoPE + KV write inside the attention kernel
+            Prof p(e, K_ATTN, s);
+            AttnArgs aa{nullptr, kvL, g.dm.row_stream, g.dm.row_pos, e->d_block_table, e->max_blocks, g.att, M, max_chunks, g.qkv, kvL, e->cos_t, e->sin_t};
+            HIP_TRY(launch_attention(aa, s));
+        } else {
+            { Prof p(e, K_ROPE, s); RopeArgs ra{g.qkv, g.qrot, kvL, g.dm.row_stream, g.dm.row_pos, e->d_block_table, e->max_blocks, e->cos_t, e->sin_t, M}; HIP_TRY(launch_rope_kv(ra, s)); }
+            { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot, kvL, g.dm.row_stream, g.dm.row_pos, e->d_block_table, e->max_blocks, g.att, M, max_chunks, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(launch_attention(aa, s)); }
+        }
+        { Prof p(e, K_O, s); GemmArgs a{g.att, (const uint4*)y.o, M, D, D, g.part, D, 4}; HIP_TRY(launch_gemm(a, EPI_F32, choose_mt(M, D / 16), s)); }
+        { Prof p(e, K_NORM, s); HIP_TRY(launch_add_rmsnorm(g.h, g.part, M, y.ln2, g.xn, M, nullptr, s)); }
+        { Prof p(e, K_GU, s); GemmArgs a{g.xn, (const uint4*)y.gu, M, D, F, g.act, F, 1}; HIP_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, F / 16), s)); }
+        { Prof p(e, K_DOWN, s); GemmArgs a{g.act, (const uint4*)y.down, M, F, D, g.part, D, 4}; HIP_TRY(launch_gemm(a, EPI_F32, choose_mt(M, D / 16), s)); }
+    }
+    if (n_sel > 0) {
+        { Prof p(e, K_NORM, s); HIP_TRY(launch_add_rmsnorm(g.h, g.part, M, e->norm, g.xlast, 2 * n_sel, g.dm.sel_rows, s)); }
+        { Prof p(e, K_HEAD, s); GemmArgs a{g.xlast, (const uint4*)e->head, 2 * n_sel, D, V, g.logits, VPAD, 1}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16), s)); }
+        { Prof p(e, K_SAMPLE, s); SampleArgs sa{g.logits, VPAD, g.dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, g.dm.out_tok, e->d_dbg, n_sel}; HIP_TRY(launch_sampler(sa, s)); }
+    }
+    return T3_OK;
+}
 
 extern "C" int t3_step(T3Handle e, T3StepResult* res) {
     if (!e) return T3_E_INVALID;
@@ -437,76 +511,76 @@ extern "C" int t3_step(T3Handle e, T3StepResult* res) {
     int rc;
     if ((rc = admit(e))) return rc;
 
-    // ---- build rows: decode rows of every running utterance, then prefill rows within the budget
-    int M = 0, n_sel = 0, n_prefill_rows = 0;
-    double sum_ctx = 0;
-    std::vector<Request*> sampled;
-    auto add_row = [&](int stream, int pos, int kind, int a, int b) {
-        e->hm.row_stream[M] = stream; e->hm.row_pos[M] = pos; e->hm.desc[M] = make_int4(kind, a, b, 0); ++M;
+    // ---- build rows per group: decode rows of every running utterance, then prefill rows within the group's budget
+    for (auto& g : e->groups) { g.M = g.n_sel = g.n_prefill_rows = g.decode_rows = 0; g.sum_ctx = 0; g.sampled.clear(); }
+    auto add_row = [&](T3Engine::Group& g, int stream, int pos, int kind, int a, int b) {
+        g.hm.row_stream[g.M] = stream; g.hm.row_pos[g.M] = pos; g.hm.desc[g.M] = make_int4(kind, a, b, 0); ++g.M;
     };
     for (int64_t id : e->running) {
         Request& r = e->reqs[id];
         if (r.state != DECODE) continue;
+        auto& g = e->groups[r.slot % e->n_groups];
         const int T = (int)r.prompt.size(), n = (int)r.out.size();
         const int pos = T - 1 + n, spos = r.sp.pos_policy == 0 ? (n % 4100) : 0;
-        e->hm.sel_rows[2 * n_sel] = M;     add_row(2 * r.slot, pos, EMB_SPEECH, r.out.back(), spos);
-        e->hm.sel_rows[2 * n_sel + 1] = M; add_row(2 * r.slot + 1, pos, EMB_SPEECH, r.out.back(), spos);
-        e->hm.sel[n_sel] = make_int4(r.slot, n, 0, 0);
-        sum_ctx += 2.0 * (pos + 1);
-        sampled.push_back(&r); ++n_sel;
+        g.hm.sel_rows[2 * g.n_sel] = g.M;     add_row(g, 2 * r.slot, pos, EMB_SPEECH, r.out.back(), spos);
+        g.hm.sel_rows[2 * g.n_sel + 1] = g.M; add_row(g, 2 * r.slot + 1, pos, EMB_SPEECH, r.out.back(), spos);
+        g.hm.sel[g.n_sel] = make_int4(r.slot, n, 0, 0);
+        g.sum_ctx += 2.0 * (pos + 1);
+        g.sampled.push_back(&r); ++g.n_sel;
     }
-    const int decode_rows = M;
+    for (auto& g : e->groups) g.decode_rows = g.M;
     for (int64_t id : e->running) {
         Request& r = e->reqs[id];
         if (r.state != PREFILL) continue;
+        auto& g = e->groups[r.slot % e->n_groups];
         const int T = (int)r.prompt.size();
-        const int chunk = std::min(T - r.n_prefilled, (e->rmax - M) / 2);
-        if (chunk <= 0) break;
+        const int chunk = std::min(T - r.n_prefilled, (g.rcap - g.M) / 2);
+        if (chunk <= 0) continue;
         const int p0 = r.n_prefilled, p1 = p0 + chunk;
-        for (int s = 0; s < 2; ++s)
+        for (int sI = 0; sI < 2; ++sI)
             for (int p = p0; p < p1; ++p) {
-                if (p < T3_COND_ROWS) add_row(2 * r.slot + s, p, EMB_COND, r.slot, p);
-                else if (p < T - 1) { if (s == 0) add_row(2 * r.slot, p, EMB_TEXT, r.prompt[p], p - T3_COND_ROWS); else add_row(2 * r.slot + 1, p, EMB_ZERO, 0, 0); }
-                else add_row(2 * r.slot + s, p, EMB_SPEECH, 6561, 0);      // BOS: speech_emb[start] + speech_pos[0], t3.py:550-551
-                if (p == T - 1) e->hm.sel_rows[2 * n_sel + s] = M - 1;
+                if (p < T3_COND_ROWS) add_row(g, 2 * r.slot + sI, p, EMB_COND, r.slot, p);
+                else if (p < T - 1) { if (sI == 0) add_row(g, 2 * r.slot, p, EMB_TEXT, r.prompt[p], p - T3_COND_ROWS); else add_row(g, 2 * r.slot + 1, p, EMB_ZERO, 0, 0); }
+                else add_row(g, 2 * r.slot + sI, p, EMB_SPEECH, 6561, 0);      // BOS: speech_emb[start] + speech_pos[0], t3.py:550-551
+                if (p == T - 1) g.hm.sel_rows[2 * g.n_sel + sI] = g.M - 1;
             }
-        r.n_prefilled = p1; n_prefill_rows += 2 * chunk;
-        if (p1 == T) { e->hm.sel[n_sel] = make_int4(r.slot, 0, 0, 0); sampled.push_back(&r); ++n_sel; }
+        r.n_prefilled = p1; g.n_prefill_rows += 2 * chunk;
+        if (p1 == T) { g.hm.sel[g.n_sel] = make_int4(r.slot, 0, 0, 0); g.sampled.push_back(&r); ++g.n_sel; }
     }
-    res->n_rows = M; res->n_prefill_rows = n_prefill_rows; res->n_sampled = n_sel;
-    if (M == 0) { res->n_running = (int)e->running.size(); res->n_waiting = (int)e->waiting.size(); return T3_OK; }
+    int M_all = 0, n_prefill_rows = 0, decode_rows = 0; double sum_ctx = 0;
+    for (auto& g : e->groups) { M_all += g.M; n_prefill_rows += g.n_prefill_rows; res->n_sampled += g.n_sel; decode_rows += g.decode_rows; sum_ctx += g.sum_ctx; }
+    res->n_rows = M_all; res->n_prefill_rows = n_prefill_rows;
+    if (M_all == 0) { res->n_running = (int)e->running.size(); res->n_waiting = (int)e->waiting.size(); return T3_OK; }
 
-    HIP_TRY(hipMemcpyAsync(e->d_meta, e->h_meta, e->meta_bytes, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    hipStream_t s = e->stream;
-    {
-        Prof p(e, K_EMBED);
-        EmbedArgs ea{e->dm.desc, e->d_cond, e->text_emb, e->text_pos, e->speech_emb, e->speech_pos, e->h, M};
-        HIP_TRY(launch_embed(ea, s));
+    const auto t_begin = std::chrono::steady_clock::now();
+    for (auto& g : e->groups) {
+        if (g.M == 0) continue;
+        HIP_TRY(hipStreamWaitEvent(g.stream, e->ev_admit, 0));
+        HIP_TRY(hipMemcpyAsync(g.d_meta, g.h_meta, g.meta_bytes, hipMemcpyHostToDevice, g.stream));
+        const bool use_graph = !e->cfg.enforce_eager && !e->profile && g.n_prefill_rows == 0;
+        if (use_graph) {
+            const auto key = std::make_pair(g.M, g.n_sel);
+            auto it = g.graphs.find(key);
+            if (it == g.graphs.end()) {
+                hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+                HIP_TRY(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+                const int lrc = launch_step(e, g);
+                const hipError_t ce = hipStreamEndCapture(g.stream, &graph);
+                if (lrc) return lrc;
+                HIP_TRY(ce);
+                HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                if (g.graphs.size() > 64) { for (auto& kv : g.graphs) (void)hipGraphExecDestroy(kv.second); g.graphs.clear(); }
+                it = g.graphs.emplace(key, exec).first;
+            }
+            HIP_TRY(hipGraphLaunch(it->second, g.stream));
+        } else {
+            if ((rc = launch_step(e, g))) return rc;
+        }
+        if (g.n_sel > 0) HIP_TRY(hipMemcpyAsync(g.h_out_tok, g.dm.out_tok, (size_t)g.n_sel * 4, hipMemcpyDeviceToHost, g.stream));
     }
-    const size_t layer_elems = (size_t)e->n_blocks * KV_BLOCK_ELEMS;
-    for (int L = 0; L < e->cfg.n_layers; ++L) {
-        LayerW& y = e->layers[L];
-        uint16_t* kvL = e->kv + (size_t)L * layer_elems;
-        // previous layer's down_proj slabs are folded into the residual stream here
-        { Prof p(e, K_NORM); HIP_TRY(launch_add_rmsnorm(e->h, L ? e->part : nullptr, M, y.ln1, e->xn, M, nullptr, s)); }
-        { Prof p(e, K_QKV); GemmArgs g{e->xn, (const uint4*)y.qkv, M, D, QKV, e->qkv, QKV, 1}; HIP_TRY(launch_gemm(g, EPI_BF16, choose_mt(M, QKV / 16), s)); }
-        { Prof p(e, K_ROPE); RopeArgs ra{e->qkv, e->qrot, kvL, e->dm.row_stream, e->dm.row_pos, e->d_block_table, e->max_blocks, e->cos_t, e->sin_t, M}; HIP_TRY(launch_rope_kv(ra, s)); }
-        { Prof p(e, K_ATTN); AttnArgs aa{e->qrot, kvL, e->dm.row_stream, e->dm.row_pos, e->d_block_table, e->max_blocks, e->att, M, e->max_blocks}; HIP_TRY(launch_attention(aa, s)); }
-        { Prof p(e, K_O); GemmArgs g{e->att, (const uint4*)y.o, M, D, D, e->part, D, 4}; HIP_TRY(launch_gemm(g, EPI_F32, choose_mt(M, D / 16), s)); }
-        { Prof p(e, K_NORM); HIP_TRY(launch_add_rmsnorm(e->h, e->part, M, y.ln2, e->xn, M, nullptr, s)); }
-        { Prof p(e, K_GU); GemmArgs g{e->xn, (const uint4*)y.gu, M, D, F, e->act, F, 1}; HIP_TRY(launch_gemm(g, EPI_SILU, choose_mt(M, F / 16), s)); }
-        { Prof p(e, K_DOWN); GemmArgs g{e->act, (const uint4*)y.down, M, F, D, e->part, D, 4}; HIP_TRY(launch_gemm(g, EPI_F32, choose_mt(M, D / 16), s)); }
-    }
-    if (n_sel > 0) {
-        { Prof p(e, K_NORM); HIP_TRY(launch_add_rmsnorm(e->h, e->part, M, e->norm, e->xlast, 2 * n_sel, e->dm.sel_rows, s)); }
-        { Prof p(e, K_HEAD); GemmArgs g{e->xlast, (const uint4*)e->head, 2 * n_sel, D, V, e->logits, VPAD, 1}; HIP_TRY(launch_gemm(g, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16), s)); }
-        { Prof p(e, K_SAMPLE); SampleArgs sa{e->logits, VPAD, e->dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, e->dm.out_tok, e->d_dbg, n_sel}; HIP_TRY(launch_sampler(sa, s)); }
-        HIP_TRY(hipMemcpyAsync(e->h_out_tok, e->dm.out_tok, (size_t)n_sel * 4, hipMemcpyDeviceToHost, s));
-    }
-    HIP_TRY(hipEventRecord(e->ev1, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    float ms = 0; (void)hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    for (auto& g : e->groups) if (g.M) HIP_TRY(hipStreamSynchronize(g.stream));
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     const bool decode_only = (n_prefill_rows == 0);
     e->st.steps++; e->st.gpu_ms_total += ms; e->st.prefill_rows += n_prefill_rows; e->st.decode_rows += decode_rows;
     if (decode_only) {
@@ -523,20 +597,21 @@ extern "C" int t3_step(T3Handle e, T3StepResult* res) {
         }
     }
     // ---- host bookkeeping
-    for (int i = 0; i < n_sel; ++i) {
-        Request& r = *sampled[i];
-        const int tok = e->h_out_tok[i];
-        r.out.push_back(tok); r.state = DECODE; e->st.tokens_generated++;
-        int fin = 0;
-        if (!r.sp.ignore_eos && tok == r.sp.stop_token) fin = 1;
-        else if ((int)r.out.size() >= r.limit) fin = 2;
-        if (fin) {
-            r.state = FINISHED; r.finish_reason = fin;
-            if (res->n_finished < 64) res->finished_ids[res->n_finished] = r.id;
-            res->n_finished++;
-            release_slot(e, r);
+    for (auto& g : e->groups)
+        for (int i = 0; i < g.n_sel; ++i) {
+            Request& r = *g.sampled[i];
+            const int tok = g.h_out_tok[i];
+            r.out.push_back(tok); r.state = DECODE; e->st.tokens_generated++;
+            int fin = 0;
+            if (!r.sp.ignore_eos && tok == r.sp.stop_token) fin = 1;
+            else if ((int)r.out.size() >= r.limit) fin = 2;
+            if (fin) {
+                r.state = FINISHED; r.finish_reason = fin;
+                if (res->n_finished < 64) res->finished_ids[res->n_finished] = r.id;
+                res->n_finished++;
+                release_slot(e, r);
+            }
         }
-    }
     if (res->n_finished) e->running.erase(std::remove_if(e->running.begin(), e->running.end(), [&](int64_t id) { return e->reqs[id].state == FINISHED; }), e->running.end());
     res->n_running = (int)e->running.size(); res->n_waiting = (int)e->waiting.size();
     return T3_OK;

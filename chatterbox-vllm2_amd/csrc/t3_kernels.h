@@ -8,7 +8,11 @@
 namespace t3 {
 
 constexpr int D = 1024, H = 16, HD = 64, F = 4096, V = 8194, VPAD = 8208, QKV = 3072;
-constexpr int KV_BLOCK = 64;                       // tokens per KV block == attention chunk
+constexpr int CHUNK = 64;                          // attention chunk in tokens (numerics contract)
+#ifndef T3_KV_BLOCK
+#define T3_KV_BLOCK 256
+#endif
+constexpr int KV_BLOCK = T3_KV_BLOCK;              // tokens per physical KV block (a multiple of CHUNK): per head 32 KiB K + 32 KiB V contiguous
 constexpr int KV_BLOCK_ELEMS = 2 * H * KV_BLOCK * HD;  // per layer per block: K then V, [kv][head][tok][64]
 
 enum GemmEpi { EPI_F32 = 0, EPI_BF16 = 1, EPI_RESID = 2, EPI_SILU = 3 };
@@ -55,13 +59,17 @@ struct RopeArgs {
 hipError_t launch_rope_kv(const RopeArgs& a, hipStream_t s);
 
 struct AttnArgs {
-    const uint16_t* q;         // [rows][1024] rotated
+    const uint16_t* q;         // [rows][1024] rotated (unfused form)
     const uint16_t* kv_layer;
     const int *row_stream, *row_pos, *block_table;
     int max_blocks;
     uint16_t* out;             // [rows][1024]
     int rows;
     int max_chunks;            // LDS sizing: ceil(max_model_len/64)
+    // fused decode form (every row is the newest position of its stream): RoPE of q,k + KV write happen here
+    const uint16_t* qkv;       // [rows][3072] pre-RoPE, or null for the unfused form
+    uint16_t* kv_layer_w;      // writable alias of kv_layer
+    const float *cos_t, *sin_t;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -77,6 +85,7 @@ struct SampleArgs {
     int n;
 };
 hipError_t launch_sampler(const SampleArgs& a, hipStream_t s);
+hipError_t prepare_kernels();   // one-time function attributes (must run before any stream capture)
 hipError_t launch_expf(const float* x, float* y, int n, hipStream_t s);
 
 void rope_tables(int max_pos, float* cos_t, float* sin_t);   // host, llama3 scaling, bf16-valued

@@ -88,6 +88,11 @@ __device__ __forceinline__ uint32_t silu_mul_bf(uint32_t g, uint32_t u) {   // b
 // must be issued as far ahead as the weight loads or they would drain the weight prefetch every step.
 // ------------------------------------------------------------------------------------------------
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_nt(const uint4* p) {      // streamed-once data: non-temporal load
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ bf16x8 as_frag(const uint4& v) {
     union { uint4 u; bf16x8 f; } c; c.u = v; return c.f;
 }
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(RopeArgs a) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
     const int pos = a.row_pos[row], stream = a.row_stream[row];
-    const int blk = a.block_table[(size_t)stream * a.max_blocks + (pos >> 6)], tok = pos & 63;
+    const int blk = a.block_table[(size_t)stream * a.max_blocks + pos / KV_BLOCK], tok = pos % KV_BLOCK;
     const int h = lane >> 2, part = lane & 3, i0 = part * 8;
     float c[8], s[8];
     {
@@ -422,37 +427,79 @@ hipError_t launch_rope_kv(const RopeArgs& a, hipStream_t s) {
 // Per-chunk (m_c, l_c, o_c[64]) go to LDS; wave 0 combines them in ascending chunk order.
 // All orders are the contract's (DESIGN.md "Attention").
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+template <int NW, bool NT, bool FUSE>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float part[];   // [max_chunks] m | [max_chunks] l | [max_chunks][64] o
     float* pm = part; float* pl = part + a.max_chunks; float* po = part + 2 * a.max_chunks;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = blockIdx.x, row = blockIdx.y;
     const int stream = a.row_stream[row], L = a.row_pos[row] + 1;
-    const int nc = (L + KV_BLOCK - 1) / KV_BLOCK;
+    const int nc = (L + CHUNK - 1) / CHUNK;
     const int g = lane >> 3, e8 = lane & 7;
     float qf[8];
-    unpack8(*reinterpret_cast<const uint4*>(a.q + (size_t)row * D + h * HD + e8 * 8), qf);
     const int* bt = a.block_table + (size_t)stream * a.max_blocks;
+    float kn[8], vn[8];                 // FUSE: the row's own (newest) key / value, dims 8*e8..8*e8+7
+    if constexpr (FUSE) {
+        // RoPE of this head's q and k exactly as rope_kv_kernel does it (same products, same roundings), then the
+        // paged K/V write; the newest token is taken from registers below instead of being re-read from HBM.
+        const int pos = L - 1;
+        const uint16_t* src = a.qkv + (size_t)row * QKV + h * HD + e8 * 8;
+        float xq[8], xk[8], c[8], s[8];
+        unpack8(*reinterpret_cast<const uint4*>(src), xq);
+        unpack8(*reinterpret_cast<const uint4*>(src + D), xk);
+        unpack8(*reinterpret_cast<const uint4*>(src + 2 * D), vn);
+        const float4* cp = reinterpret_cast<const float4*>(a.cos_t + (size_t)pos * 32 + (e8 & 3) * 8);
+        const float4* sp = reinterpret_cast<const float4*>(a.sin_t + (size_t)pos * 32 + (e8 & 3) * 8);
+        const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+        c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+        s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
+        const bool upper = e8 >= 4;     // dims 32..63 pair with dims 0..31 held by lane ^ 4
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float pq = __shfl_xor(xq[e], 4), pk = __shfl_xor(xk[e], 4);
+            // lower: x1*c - x2*s ; upper: x2*c + x1*s   (x1 = lower half, x2 = upper half)
+            const float rq = upper ? (xq[e] * c[e] + pq * s[e]) : (xq[e] * c[e] - pq * s[e]);
+            const float rk = upper ? (xk[e] * c[e] + pk * s[e]) : (xk[e] * c[e] - pk * s[e]);
+            qf[e] = rbf(rq); kn[e] = rbf(rk);
+        }
+        if (wave == 0 && g == 0) {
+            const int blk = bt[pos / KV_BLOCK], tok = pos % KV_BLOCK;
+            uint16_t* kb = a.kv_layer_w + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(0 * H + h) * KV_BLOCK + tok) * HD + e8 * 8;
+            uint16_t* vb = a.kv_layer_w + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(1 * H + h) * KV_BLOCK + tok) * HD + e8 * 8;
+            uint4 ko, vo;
+            ko.x = pack2(kn[0], kn[1]); ko.y = pack2(kn[2], kn[3]); ko.z = pack2(kn[4], kn[5]); ko.w = pack2(kn[6], kn[7]);
+            vo.x = pack2(vn[0], vn[1]); vo.y = pack2(vn[2], vn[3]); vo.z = pack2(vn[4], vn[5]); vo.w = pack2(vn[6], vn[7]);
+            *reinterpret_cast<uint4*>(kb) = ko; *reinterpret_cast<uint4*>(vb) = vo;
+        }
+    } else {
+        unpack8(*reinterpret_cast<const uint4*>(a.q + (size_t)row * D + h * HD + e8 * 8), qf);
+    }
 
-    for (int c = wave; c < nc; c += 4) {
-        const int blk = bt[c];
-        const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + (size_t)(0 * H + h) * KV_BLOCK * HD);
-        const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + (size_t)(1 * H + h) * KV_BLOCK * HD);
+    for (int c = wave; c < nc; c += NW) {
+        constexpr int CPB = KV_BLOCK / CHUNK;          // chunks per physical block
+        const int blk = bt[c / CPB], sub = (c % CPB) * CHUNK;
+        const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(0 * H + h) * KV_BLOCK + sub) * HD);
+        const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(1 * H + h) * KV_BLOCK + sub) * HD);
         uint4 kk[8], vv[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) kk[i] = Kp[i * 64 + lane];
+        for (int i = 0; i < 8; ++i) kk[i] = NT ? ld_nt(Kp + i * 64 + lane) : Kp[i * 64 + lane];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) vv[i] = Vp[i * 64 + lane];
+        for (int i = 0; i < 8; ++i) vv[i] = NT ? ld_nt(Vp + i * 64 + lane) : Vp[i * 64 + lane];
         float sc[8];
         float m = -INFINITY;
+        const int tnew = FUSE ? (L - 1 - c * CHUNK) : -1;          // index of the newest token inside this chunk (last chunk only)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float kf[8]; unpack8(kk[i], kf);
+            if (FUSE && tnew == 8 * i + g) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kf[e] = kn[e];
+            }
             float s = 0.0f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) s = __builtin_fmaf(qf[e], kf[e], s);
             s = s + __shfl_xor(s, 1); s = s + __shfl_xor(s, 2); s = s + __shfl_xor(s, 4);
-            const int t = c * KV_BLOCK + 8 * i + g;
+            const int t = c * CHUNK + 8 * i + g;
             sc[i] = (t < L) ? s * 0.125f : -INFINITY;
             m = fmaxf(m, sc[i]);
         }
@@ -467,7 +514,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float vf[8]; unpack8(vv[i], vf);
-            const bool valid = (c * KV_BLOCK + 8 * i + g) < L;
+            if (FUSE && tnew == 8 * i + g) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vf[e] = vn[e];
+            }
+            const bool valid = (c * CHUNK + 8 * i + g) < L;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(p[i], valid ? vf[e] : 0.0f, o[e]);
         }
@@ -499,7 +550,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
     const size_t lds = (size_t)a.max_chunks * 66 * sizeof(float);
-    hipLaunchKernelGGL(attention_kernel, dim3(H, a.rows), dim3(256), lds, s, a);
+    static int nw = 0, nt = 0;
+    if (!nw) { const char* e = getenv("T3_ATTN_WAVES"); nw = e ? atoi(e) : 4; const char* t = getenv("T3_ATTN_NT"); nt = t ? atoi(t) : 1; }
+    const dim3 grid(H, a.rows);
+    const bool fuse = a.qkv != nullptr;
+#define T3_ATTN(NW, NTF, FU) hipLaunchKernelGGL((attention_kernel<NW, NTF, FU>), grid, dim3(NW * 64), lds, s, a)
+    if (nw == 8) { if (fuse) { if (nt) T3_ATTN(8, true, true); else T3_ATTN(8, false, true); } else { if (nt) T3_ATTN(8, true, false); else T3_ATTN(8, false, false); } }
+    else { if (fuse) { if (nt) T3_ATTN(4, true, true); else T3_ATTN(4, false, true); } else { if (nt) T3_ATTN(4, true, false); else T3_ATTN(4, false, false); } }
+#undef T3_ATTN
     return hipGetLastError();
 }
 
@@ -694,15 +752,19 @@ __global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
         if (cnt < 65535) counts[token] = cnt + 1;
     }
 }
+hipError_t prepare_kernels() {
+    static bool done = false;
+    if (done) return hipSuccess;
+    const size_t lds = (size_t)(SLOTS + 8 + 256) * sizeof(unsigned long long);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) done = true;
+    return e;
+}
 hipError_t launch_sampler(const SampleArgs& a, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
     const size_t lds = (size_t)(SLOTS + 8 + 256) * sizeof(unsigned long long);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    hipError_t e = prepare_kernels();
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sampler_kernel, dim3(a.n), dim3(256), lds, s, a);
     return hipGetLastError();
 }

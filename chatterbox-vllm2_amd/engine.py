@@ -27,7 +27,7 @@ class T3EngineConfig(ct.Structure):
         ("device_id", ct.c_int32), ("n_layers", ct.c_int32), ("text_vocab", ct.c_int32),
         ("max_model_len", ct.c_int32), ("max_seqs", ct.c_int32), ("max_batched_rows", ct.c_int32),
         ("kv_bytes", ct.c_int64), ("gpu_memory_utilization", ct.c_float), ("cfg_scale", ct.c_float),
-        ("enforce_eager", ct.c_int32), ("debug_logits", ct.c_int32),
+        ("enforce_eager", ct.c_int32), ("debug_logits", ct.c_int32), ("n_groups", ct.c_int32), ("_pad", ct.c_int32),
     ]
 
 
@@ -147,13 +147,13 @@ class T3Engine:
     def __init__(self, n_layers: int = C.N_LAYERS, text_vocab: int = C.TEXT_VOCAB_EN, max_model_len: int = 1000,
                  max_seqs: int = 32, device_id: int = 0, kv_bytes: int = 0, gpu_memory_utilization: float = 0.9,
                  cfg_scale: Optional[float] = None, enforce_eager: bool = True, debug_logits: bool = False,
-                 max_batched_rows: int = 0):
+                 max_batched_rows: int = 0, n_groups: int = 0):
         self.lib = load_library()
         if cfg_scale is None:
             cfg_scale = float(os.environ.get("CHATTERBOX_CFG_SCALE", "0.5"))   # t3.py:296
         self.cfg = T3EngineConfig(device_id, n_layers, text_vocab, max_model_len, max_seqs, max_batched_rows,
                                   int(kv_bytes), float(gpu_memory_utilization), float(cfg_scale),
-                                  int(enforce_eager), int(debug_logits))
+                                  int(enforce_eager), int(debug_logits), int(n_groups), 0)
         self.h = ct.c_void_p()
         rc = self.lib.t3_create(ct.byref(self.cfg), ct.byref(self.h))
         if rc:

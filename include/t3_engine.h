@@ -51,6 +51,8 @@ typedef struct {
     float cfg_scale;           /* CHATTERBOX_CFG_SCALE, default 0.5 (t3.py:296) */
     int32_t enforce_eager;     /* 1: never use hipGraph replay (tts.py:163) */
     int32_t debug_logits;      /* 1: keep post-CFG logits of each sampled step for t3_debug_logits */
+    int32_t n_groups;          /* utterance groups run concurrently on separate HIP streams; 0 = auto */
+    int32_t _pad;
 } T3EngineConfig;
 
 /* Replaces vllm.SamplingParams as configured at tts.py:455-464 (+ the kwargs it forwards). */

@@ -93,6 +93,25 @@ def test_batch_invariance_and_continuous_batching(E, oracle, tiny_engine, tiny_o
     assert st.kv_blocks_free == st.kv_blocks_total      # every block returned
 
 
+@pytest.mark.parametrize("n_groups,eager", [(1, True), (1, False), (3, False), (4, True)])
+def test_groups_and_graph_replay_do_not_change_ids(E, oracle, tiny_weights, tiny_oracle, cond, n_groups, eager):
+    """Concurrent utterance groups (separate streams) and hipGraph replay are scheduling only: every stream still
+    equals its single-utterance oracle stream.  Requests finish at different steps, so graphs are re-captured."""
+    eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=400, max_seqs=6, kv_bytes=1 << 29, n_groups=n_groups, enforce_eager=eager)
+    eng.load_tensors(tiny_weights); eng.finalize()
+    reqs = []
+    for i in range(9):
+        prompt = make_prompt(5 + 7 * i, seed=40 + i)
+        kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=3, uid=i, max_tokens=6 + 5 * (i % 4), ignore_eos=True)
+        reqs.append((i, prompt, kw)); eng.add_request(i, prompt, cond, E.make_sampling(**kw))
+    eng.run_until_done()
+    for i, prompt, kw in reqs:
+        got, _ = eng.get_output(i)
+        want, _ = tiny_oracle.generate(prompt, cond, oracle.make_sampling(**kw), max_model_len=400)
+        assert [t - 2500 for t in got] == want, f"utterance {i} (groups={n_groups}, eager={eager})"
+    eng.close()
+
+
 def test_chunked_prefill_equals_whole(E, tiny_weights, cond):
     """A row budget smaller than one prompt forces the prompt through several steps; ids must not change."""
     outs = []
