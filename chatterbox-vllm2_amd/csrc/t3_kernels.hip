@@ -438,6 +438,18 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
     const int g = lane >> 3, e8 = lane & 7;
     float qf[8];
     const int* bt = a.block_table + (size_t)stream * a.max_blocks;
+    constexpr int CPB = KV_BLOCK / CHUNK;          // chunks per physical block
+    // the wave's first K/V tile is requested before anything else so that the q / RoPE prologue overlaps its flight
+    uint4 kk[8], vv[8];
+    if (wave < nc) {
+        const int blk = bt[wave / CPB], sub = (wave % CPB) * CHUNK;
+        const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(0 * H + h) * KV_BLOCK + sub) * HD);
+        const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(1 * H + h) * KV_BLOCK + sub) * HD);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kk[i] = NT ? ld_nt(Kp + i * 64 + lane) : Kp[i * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vv[i] = NT ? ld_nt(Vp + i * 64 + lane) : Vp[i * 64 + lane];
+    }
     float kn[8], vn[8];                 // FUSE: the row's own (newest) key / value, dims 8*e8..8*e8+7
     if constexpr (FUSE) {
         // RoPE of this head's q and k exactly as rope_kv_kernel does it (same products, same roundings), then the
@@ -476,15 +488,15 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
     }
 
     for (int c = wave; c < nc; c += NW) {
-        constexpr int CPB = KV_BLOCK / CHUNK;          // chunks per physical block
-        const int blk = bt[c / CPB], sub = (c % CPB) * CHUNK;
-        const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(0 * H + h) * KV_BLOCK + sub) * HD);
-        const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(1 * H + h) * KV_BLOCK + sub) * HD);
-        uint4 kk[8], vv[8];
+        if (c != wave) {
+            const int blk = bt[c / CPB], sub = (c % CPB) * CHUNK;
+            const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(0 * H + h) * KV_BLOCK + sub) * HD);
+            const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(1 * H + h) * KV_BLOCK + sub) * HD);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) kk[i] = NT ? ld_nt(Kp + i * 64 + lane) : Kp[i * 64 + lane];
+            for (int i = 0; i < 8; ++i) kk[i] = NT ? ld_nt(Kp + i * 64 + lane) : Kp[i * 64 + lane];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) vv[i] = NT ? ld_nt(Vp + i * 64 + lane) : Vp[i * 64 + lane];
+            for (int i = 0; i < 8; ++i) vv[i] = NT ? ld_nt(Vp + i * 64 + lane) : Vp[i * 64 + lane];
+        }
         float sc[8];
         float m = -INFINITY;
         const int tnew = FUSE ? (L - 1 - c * CHUNK) : -1;          // index of the newest token inside this chunk (last chunk only)
