@@ -185,10 +185,14 @@ def main():
             else:
                 algo = wbytes.get(dom, 0)
             ms = kern[dom][0]
+            # HBM bytes per launch from the PMC pass recorded in profiles/traffic.json (FETCH_SIZE, gfx950 x2 correction):
+            # the measured bytes/algorithmic-bytes ratio of that pass applied to this run's algorithmic bytes per launch
             traffic = None
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf):
-                traffic = json.load(open(tf)).get(dom)
+                rec = json.load(open(tf)).get(dom)
+                if rec and "ratio" in rec:
+                    traffic = round(rec["ratio"] * algo)
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "algo_bytes_per_launch": round(algo), "avg_launch_ms": round(ms, 5), "launches": kern[dom][1]}
