@@ -1,0 +1,94 @@
+"""GPU engine vs the COMMITTED golden streams (tests/golden/streams.npz, made by tests/golden/make_golden.py with the
+oracle in the build container) at the BASELINE.json config shapes -- no oracle run needed on the GPU box:
+  C1/C2: English vocab, T = 108 prompt, B = 1, greedy + the reference's sampling defaults (2-layer and the real 30-layer depth)
+  C3:    multilingual vocab, en (T = 116) + es (T = 141) prompts in one batch
+Bar: token ids equal, logits bit-identical."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from chatterbox_vllm2_amd import engine as E
+    from chatterbox_vllm2_amd.prompt import assemble_prompt_ids
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb, synthetic_tensors
+    E.load_library()
+    z = np.load(os.path.join(G, "streams.npz")); tok = json.load(open(os.path.join(G, "tokenizer.json")))
+    return dict(E=E, z=z, tok=tok, cond=synthetic_cond_emb(1), asm=assemble_prompt_ids, syn=synthetic_tensors)
+
+
+def _run(c, layers, vocab, reqs, max_model_len, want_logits_steps=()):
+    E = c["E"]
+    eng = E.T3Engine(n_layers=layers, text_vocab=vocab, max_model_len=max_model_len, max_seqs=max(2, len(reqs)), kv_bytes=2 << 30, debug_logits=True)
+    eng.load_tensors(c["syn"](layers, vocab, 1234)); eng.finalize()
+    for rid, prompt, kw in reqs:
+        eng.add_request(rid, prompt, c["cond"], E.make_sampling(**kw))
+    logits = {}
+    step = 0
+    while eng.num_unfinished():
+        r = eng.step()
+        if r.n_sampled and step in want_logits_steps and eng.num_unfinished():
+            logits[step] = eng.debug_logits(reqs[0][0])
+        step += 1 if r.n_sampled else 0
+    out = {rid: [t - 2500 for t in eng.get_output(rid)[0]] for rid, _, _ in reqs}
+    eng.close()
+    return out, logits
+
+
+def test_c1_english_two_layers(ctx):
+    p = ctx["asm"](ctx["tok"]["en_english_ids"])
+    assert len(p) == 108
+    out, lg = _run(ctx, 2, 704, [(0, p, dict(temperature=0.0, max_tokens=64, ignore_eos=True))], 400, want_logits_steps=(0, 63))
+    assert out[0] == ctx["z"]["l2_en_greedy_ids"].tolist()
+    assert np.array_equal(lg[0].numpy().view(np.int32), ctx["z"]["l2_en_greedy_logits_step0"].view(np.int32))
+    out, _ = _run(ctx, 2, 704, [(0, p, dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, uid=0, max_tokens=64, ignore_eos=True))], 400)
+    assert out[0] == ctx["z"]["l2_en_sampled_ids"].tolist()
+
+
+def test_c3_multilingual_batch(ctx):
+    en, es = ctx["asm"](ctx["tok"]["en_mtl_ids"]), ctx["asm"](ctx["tok"]["es_mtl_ids"])
+    assert (len(en), len(es)) == (116, 141)
+    kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, max_tokens=48, ignore_eos=True)
+    out, _ = _run(ctx, 2, 2454, [(0, en, dict(uid=0, **kw)), (1, es, dict(uid=1, **kw))], 400)
+    assert out[0] == ctx["z"]["l2_mtl_en_sampled_ids"].tolist()
+    assert out[1] == ctx["z"]["l2_mtl_es_sampled_ids"].tolist()
+
+
+def test_c2_full_depth_30_layers(ctx):
+    """The real model depth (30 layers, 1.07 GB of weights): ids and first-step logits against the committed oracle stream."""
+    p = ctx["asm"](ctx["tok"]["en_english_ids"])
+    out, lg = _run(ctx, 30, 704, [(0, p, dict(temperature=0.0, max_tokens=16, ignore_eos=True))], 200, want_logits_steps=(0,))
+    assert out[0] == ctx["z"]["l30_en_greedy_ids"].tolist()
+    assert np.array_equal(lg[0].numpy().view(np.int32), ctx["z"]["l30_en_greedy_logits_step0"].view(np.int32))
+    out, _ = _run(ctx, 30, 704, [(0, p, dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, uid=0, max_tokens=16, ignore_eos=True))], 200)
+    assert out[0] == ctx["z"]["l30_en_sampled_ids"].tolist()
+
+
+def test_full_size_batch_invariance_c3(ctx):
+    """BASELINE size (30 layers, B = 32, max_model_len 1000): an utterance's stream does not depend on its batch
+    (size-independent property; 24 tokens).  Also exercises hipGraph replay at full size."""
+    E = ctx["E"]
+    en, es = ctx["asm"](ctx["tok"]["en_mtl_ids"]), ctx["asm"](ctx["tok"]["es_mtl_ids"])
+    eng = E.T3Engine(n_layers=30, text_vocab=2454, max_model_len=1000, max_seqs=32, kv_bytes=10 << 30, enforce_eager=False, max_batched_rows=8192)
+    eng.load_tensors(ctx["syn"](30, 2454, 1234)); eng.finalize()
+    kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, max_tokens=24, ignore_eos=True)
+    for i in range(32):
+        eng.add_request(i, en if i < 16 else es, ctx["cond"], E.make_sampling(uid=i, **kw))
+    eng.run_until_done()
+    batch = {i: eng.get_output(i)[0] for i in range(32)}
+    for i in range(32):
+        eng.release(i)
+    for i in (0, 17, 31):
+        eng.add_request(100 + i, en if i < 16 else es, ctx["cond"], E.make_sampling(uid=i, **kw))
+        eng.run_until_done()
+        assert eng.get_output(100 + i)[0] == batch[i], f"utterance {i} differs between B=32 and B=1"
+        eng.release(100 + i)
+    assert len({tuple(v) for v in batch.values()}) == 32        # distinct uids -> distinct streams
+    eng.close()
