@@ -116,10 +116,16 @@ def main():
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the T3 engine has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # T3_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box); default RCCL
+    backend = os.environ.get("T3_BENCH_BACKEND", "nccl")
+    dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def sync():
         torch.cuda.synchronize()
@@ -136,12 +142,12 @@ def main():
     weights = list(synthetic_tensors(args.layers, 2454, 1234))
     cond = synthetic_cond_emb(1)
     eng = E.T3Engine(n_layers=args.layers, text_vocab=2454, max_model_len=args.max_model_len, max_seqs=args.batch,
-                     device_id=local_rank, gpu_memory_utilization=0.5, max_batched_rows=8192, enforce_eager=bool(int(os.environ.get('T3_EAGER', '0'))))
+                     device_id=dev, gpu_memory_utilization=0.5 / max(1, (world if backend != 'nccl' else 1)), max_batched_rows=8192, enforce_eager=bool(int(os.environ.get('T3_EAGER', '0'))))
     eng.load_tensors(weights); eng.finalize()
     reqs = build_requests(E, args, rank)
 
     res = run_pass(eng, reqs, cond, args.warmup, args.steps, sync, profile=False)
-    t = torch.tensor([res["dt"]], dtype=torch.float64, device="cuda")
+    t = torch.tensor([res["dt"]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
