@@ -86,8 +86,7 @@ struct T3Engine {
     struct Meta { int* row_stream; int* row_pos; int4* desc; int* sel_rows; int4* sel; int* out_tok; };
     struct Group {
         hipStream_t stream = nullptr;
-        uint16_t *h = nullptr, *xn = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *act = nullptr, *xlast = nullptr, *logits = nullptr;
-        float* part = nullptr;     // [4][rcap][1024] fp32 split-K slabs of o_proj / down_proj
+        uint16_t *h = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *act = nullptr, *logits = nullptr;
         char *h_meta = nullptr, *d_meta = nullptr;
         size_t meta_bytes = 0;
         Meta hm{}, dm{};
@@ -180,8 +179,8 @@ extern "C" int t3_destroy(T3Handle e) {
     for (auto& g : e->groups) {
         if (g.stream) (void)hipStreamSynchronize(g.stream);
         for (auto& kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
-        free_dev(g.h); free_dev(g.xn); free_dev(g.qkv); free_dev(g.qrot); free_dev(g.att); free_dev(g.act); free_dev(g.xlast); free_dev(g.logits);
-        free_dev(g.part); free_dev(g.d_meta); free_dev(g.dm.out_tok);
+        free_dev(g.h); free_dev(g.qkv); free_dev(g.qrot); free_dev(g.att); free_dev(g.act); free_dev(g.logits);
+        free_dev(g.d_meta); free_dev(g.dm.out_tok);
         if (g.h_meta) (void)hipHostFree(g.h_meta);
         if (g.h_out_tok) (void)hipHostFree(g.h_out_tok);
         if (g.stream) (void)hipStreamDestroy(g.stream);
@@ -329,13 +328,10 @@ extern "C" int t3_finalize_weights(T3Handle e) {
         g.rcap = std::max((int)(2 * Sg), e->rmax / e->n_groups);
         const size_t R = (size_t)g.rcap;
         if ((rc = dalloc(e, &g.h, R * D, true))) return rc;
-        if ((rc = dalloc(e, &g.xn, R * D, true))) return rc;
         if ((rc = dalloc(e, &g.qkv, R * QKV, true))) return rc;
         if ((rc = dalloc(e, &g.qrot, R * D, true))) return rc;
         if ((rc = dalloc(e, &g.att, R * D, true))) return rc;
         if ((rc = dalloc(e, &g.act, R * F, true))) return rc;
-        if ((rc = dalloc(e, &g.part, 4 * R * D, true))) return rc;
-        if ((rc = dalloc(e, &g.xlast, 2 * Sg * D, true))) return rc;
         if ((rc = dalloc(e, &g.logits, 2 * Sg * VPAD, true))) return rc;
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -473,13 +469,12 @@ static int launch_step(T3Engine* e, T3Engine::Group& g) {
         HIP_TRY(launch_embed(ea, s));
     }
     const size_t layer_elems = (size_t)e->n_blocks * KV_BLOCK_ELEMS;
+    const int max_chunks = (e->cfg.max_model_len + CHUNK - 1) / CHUNK;
     for (int L = 0; L < e->cfg.n_layers; ++L) {
         LayerW& y = e->layers[L];
         uint16_t* kvL = e->kv + (size_t)L * layer_elems;
-        // previous layer's down_proj slabs are folded into the residual stream here
-        { Prof p(e, K_NORM, s); HIP_TRY(launch_add_rmsnorm(g.h, L ? g.part : nullptr, M, y.ln1, g.xn, M, nullptr, s)); }
-        { Prof p(e, K_QKV, s); GemmArgs a{g.xn, (const uint4*)y.qkv, M, D, QKV, g.qkv, QKV, 1}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16), s)); }
-        const int max_chunks = (e->cfg.max_model_len + CHUNK - 1) / CHUNK;
+        // 5 launches per layer: RMSNorm is folded into the qkv / gate-up GEMMs, the residual add into the o / down GEMMs
+        { Prof p(e, K_QKV, s); GemmArgs a{g.h, (const uint4*)y.qkv, M, D, QKV, g.qkv, QKV, 4, y.ln1, nullptr}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s)); }
         if (g.n_prefill_rows == 0 && e->fuse_rope) {
             // decode-only step: every row is the newest position of its stream -> RoPE + KV write inside the attention kernel
             Prof p(e, K_ATTN, s);
@@ -489,14 +484,13 @@ static int launch_step(T3Engine* e, T3Engine::Group& g) {
             { Prof p(e, K_ROPE, s); RopeArgs ra{g.qkv, g.qrot, kvL, g.dm.row_stream, g.dm.row_pos, e->d_block_table, e->max_blocks, e->cos_t, e->sin_t, M}; HIP_TRY(launch_rope_kv(ra, s)); }
             { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot, kvL, g.dm.row_stream, g.dm.row_pos, e->d_block_table, e->max_blocks, g.att, M, max_chunks, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(launch_attention(aa, s)); }
         }
-        { Prof p(e, K_O, s); GemmArgs a{g.att, (const uint4*)y.o, M, D, D, g.part, D, 4}; HIP_TRY(launch_gemm(a, EPI_F32, choose_mt(M, D / 16), s)); }
-        { Prof p(e, K_NORM, s); HIP_TRY(launch_add_rmsnorm(g.h, g.part, M, y.ln2, g.xn, M, nullptr, s)); }
-        { Prof p(e, K_GU, s); GemmArgs a{g.xn, (const uint4*)y.gu, M, D, F, g.act, F, 1}; HIP_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, F / 16), s)); }
-        { Prof p(e, K_DOWN, s); GemmArgs a{g.act, (const uint4*)y.down, M, F, D, g.part, D, 4}; HIP_TRY(launch_gemm(a, EPI_F32, choose_mt(M, D / 16), s)); }
+        { Prof p(e, K_O, s); GemmArgs a{g.att, (const uint4*)y.o, M, D, D, g.h, D, 16, nullptr, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
+        { Prof p(e, K_GU, s); GemmArgs a{g.h, (const uint4*)y.gu, M, D, F, g.act, F, 4, y.ln2, nullptr}; HIP_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s)); }
+        { Prof p(e, K_DOWN, s); GemmArgs a{g.act, (const uint4*)y.down, M, F, D, g.h, D, 16, nullptr, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
     }
     if (n_sel > 0) {
-        { Prof p(e, K_NORM, s); HIP_TRY(launch_add_rmsnorm(g.h, g.part, M, e->norm, g.xlast, 2 * n_sel, g.dm.sel_rows, s)); }
-        { Prof p(e, K_HEAD, s); GemmArgs a{g.xlast, (const uint4*)e->head, 2 * n_sel, D, V, g.logits, VPAD, 1}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16), s)); }
+        // final RMSNorm folded into the speech-head GEMM, which gathers the sampled rows itself
+        { Prof p(e, K_HEAD, s); GemmArgs a{g.h, (const uint4*)e->head, 2 * n_sel, D, V, g.logits, VPAD, 4, e->norm, g.dm.sel_rows}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16, 4, true), s)); }
         { Prof p(e, K_SAMPLE, s); SampleArgs sa{g.logits, VPAD, g.dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, g.dm.out_tok, e->d_dbg, n_sel}; HIP_TRY(launch_sampler(sa, s)); }
     }
     return T3_OK;

@@ -32,64 +32,65 @@ bool have_device() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n 
 
 #define K_TRY(expr) do { if ((expr) != hipSuccess) return T3_E_DEVICE; } while (0)
 
-extern "C" int t3k_gemm(const void* x, const void* w, int32_t M, int32_t K, int32_t N, float* out, int32_t mt, int32_t ksplit) {
-    if (!x || !w || !out || M <= 0 || N <= 0 || (ksplit != 1 && ksplit != 4) || K % (128 * ksplit)) return T3_E_INVALID;
+extern "C" int t3k_gemm(const void* x, const void* w, int32_t M, int32_t K, int32_t N, float* out, int32_t mt, int32_t nw) {
+    if (!x || !w || !out || M <= 0 || N <= 0 || (nw != 4 && nw != 16) || K % (32 * nw)) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
     const int Npad = (N + 15) / 16 * 16;
     std::vector<uint16_t> packed((size_t)Npad * K);
     pack_weight((const uint16_t*)w, N, K, Npad, packed.data());
     DevBuf dx, dw, dout;
-    K_TRY(dx.from(x, (size_t)M * K * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)ksplit * M * N * 4, true));
-    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, K, N, dout.p, N, ksplit};
-    K_TRY(launch_gemm(a, EPI_F32, mt > 0 ? mt : choose_mt(M, Npad / 16), nullptr));
+    K_TRY(dx.from(x, (size_t)M * K * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * N * 4, true));
+    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, K, N, dout.p, N, nw, nullptr, nullptr};
+    K_TRY(launch_gemm(a, EPI_F32, mt > 0 ? mt : choose_mt(M, Npad / 16, nw, false), nullptr));
     K_TRY(hipDeviceSynchronize());
-    if (ksplit == 1) { K_TRY(hipMemcpy(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost)); return T3_OK; }
-    // fold the four slabs the way add_rmsnorm_kernel does: ((G0 + G1) + G2) + G3
-    std::vector<float> slabs((size_t)4 * M * N);
-    K_TRY(hipMemcpy(slabs.data(), dout.p, slabs.size() * 4, hipMemcpyDeviceToHost));
-    const size_t sl = (size_t)M * N;
-    for (size_t i = 0; i < sl; ++i) {
-        volatile float t = slabs[i] + slabs[sl + i];
-        t = t + slabs[2 * sl + i];
-        t = t + slabs[3 * sl + i];
-        out[i] = t;
-    }
+    K_TRY(hipMemcpy(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     return T3_OK;
 }
 
-extern "C" int t3k_rmsnorm(const void* x, const void* w, void* y, int32_t rows) {
-    if (!x || !w || !y || rows <= 0) return T3_E_INVALID;
+/* RMSNorm folded into the GEMM: out[r][n] = rstd * GEMM(bf16(h[row_index[r]] * ln_w), W); h [Mh][1024] */
+extern "C" int t3k_norm_gemm(const void* h, const void* ln_w, const void* w, int32_t M, int32_t N, float* out,
+                             const int32_t* row_index, int32_t Mh) {
+    if (!h || !ln_w || !w || !out || M <= 0 || N <= 0 || Mh <= 0) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
-    DevBuf dx, dw, dy;
-    K_TRY(dx.from(x, (size_t)rows * D * 2)); K_TRY(dw.from(w, D * 2)); K_TRY(dy.alloc((size_t)rows * D * 2));
-    K_TRY(launch_add_rmsnorm(dx.as<uint16_t>(), nullptr, rows, dw.as<uint16_t>(), dy.as<uint16_t>(), rows, nullptr, nullptr));
+    const int Npad = (N + 15) / 16 * 16;
+    std::vector<uint16_t> packed((size_t)Npad * D);
+    pack_weight((const uint16_t*)w, N, D, Npad, packed.data());
+    DevBuf dh, dl, dw, dout, dri;
+    K_TRY(dh.from(h, (size_t)Mh * D * 2)); K_TRY(dl.from(ln_w, D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2));
+    K_TRY(dout.alloc((size_t)M * N * 4, true));
+    if (row_index) K_TRY(dri.from(row_index, (size_t)M * 4));
+    GemmArgs a{dh.as<uint16_t>(), dw.as<uint4>(), M, D, N, dout.p, N, 4, dl.as<uint16_t>(), row_index ? dri.as<int>() : nullptr};
+    K_TRY(launch_gemm(a, EPI_F32, choose_mt(M, Npad / 16, 4, true), nullptr));
     K_TRY(hipDeviceSynchronize());
-    K_TRY(hipMemcpy(y, dy.p, (size_t)rows * D * 2, hipMemcpyDeviceToHost));
+    K_TRY(hipMemcpy(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     return T3_OK;
 }
 
-/* h [rows][1024] bf16 (updated), P [4][rows][1024] fp32, w [1024] -> y = RMSNorm(h + bf16(fold(P))) * w */
-extern "C" int t3k_add_rmsnorm(void* h, const float* P, const void* w, void* y, int32_t rows) {
-    if (!h || !P || !w || !y || rows <= 0) return T3_E_INVALID;
+/* residual epilogue of the o_proj / down_proj form: h [M][N] bf16 updated in place: h = bf16(h + bf16(x W^T)) */
+extern "C" int t3k_gemm_resid(const void* x, const void* w, int32_t M, int32_t K, int32_t N, void* h_bf16) {
+    if (!x || !w || !h_bf16 || M <= 0 || N <= 0 || N % 16 || K % 512) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
-    DevBuf dh, dp, dw, dy;
-    K_TRY(dh.from(h, (size_t)rows * D * 2)); K_TRY(dp.from(P, (size_t)4 * rows * D * 4)); K_TRY(dw.from(w, D * 2)); K_TRY(dy.alloc((size_t)rows * D * 2));
-    K_TRY(launch_add_rmsnorm(dh.as<uint16_t>(), dp.as<float>(), rows, dw.as<uint16_t>(), dy.as<uint16_t>(), rows, nullptr, nullptr));
+    std::vector<uint16_t> packed((size_t)N * K);
+    pack_weight((const uint16_t*)w, N, K, N, packed.data());
+    DevBuf dx, dw, dh;
+    K_TRY(dx.from(x, (size_t)M * K * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dh.from(h_bf16, (size_t)M * N * 2));
+    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, K, N, dh.p, N, 16, nullptr, nullptr};
+    K_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, N / 16, 16, false), nullptr));
     K_TRY(hipDeviceSynchronize());
-    K_TRY(hipMemcpy(y, dy.p, (size_t)rows * D * 2, hipMemcpyDeviceToHost));
-    K_TRY(hipMemcpy(h, dh.p, (size_t)rows * D * 2, hipMemcpyDeviceToHost));
+    K_TRY(hipMemcpy(h_bf16, dh.p, (size_t)M * N * 2, hipMemcpyDeviceToHost));
     return T3_OK;
 }
 
-extern "C" int t3k_silu_mul_gemm(const void* x, const void* wg, const void* wu, int32_t M, int32_t Fd, void* out) {
-    if (!x || !wg || !wu || !out || M <= 0 || Fd <= 0 || Fd % 16) return T3_E_INVALID;
+/* gate/up form: out = bf16( bf16(silu(g)) * u ), g/u = bf16(rstd * GEMM(bf16(h*ln_w), Wg/Wu)) */
+extern "C" int t3k_silu_mul_gemm(const void* h, const void* ln_w, const void* wg, const void* wu, int32_t M, int32_t Fd, void* out) {
+    if (!h || !ln_w || !wg || !wu || !out || M <= 0 || Fd <= 0 || Fd % 16) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
     std::vector<uint16_t> packed((size_t)2 * Fd * D);
     pack_gate_up((const uint16_t*)wg, (const uint16_t*)wu, Fd, D, packed.data());
-    DevBuf dx, dw, dout;
-    K_TRY(dx.from(x, (size_t)M * D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * Fd * 2, true));
-    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, D, Fd, dout.p, Fd, 1};
-    K_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, Fd / 16), nullptr));
+    DevBuf dx, dl, dw, dout;
+    K_TRY(dx.from(h, (size_t)M * D * 2)); K_TRY(dl.from(ln_w, D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * Fd * 2, true));
+    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, D, Fd, dout.p, Fd, 4, dl.as<uint16_t>(), nullptr};
+    K_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, Fd / 16, 4, true), nullptr));
     K_TRY(hipDeviceSynchronize());
     K_TRY(hipMemcpy(out, dout.p, (size_t)M * Fd * 2, hipMemcpyDeviceToHost));
     return T3_OK;

@@ -18,12 +18,14 @@ constexpr int KV_BLOCK_ELEMS = 2 * H * KV_BLOCK * HD;  // per layer per block: K
 enum GemmEpi { EPI_F32 = 0, EPI_BF16 = 1, EPI_RESID = 2, EPI_SILU = 3 };
 
 struct GemmArgs {
-    const uint16_t* X;   // [M][K] bf16 row-major
+    const uint16_t* X;   // [M][K] bf16 row-major (NORM form: the un-normalised residual stream)
     const uint4* Wp;     // packed weight, see pack_weight()
     int M, K, N;         // N = number of valid output columns (EPI_SILU: F)
     void* out;           // EPI_F32: float [M][ldo]; else bf16 [M][ldo]; EPI_RESID: residual stream, updated in place
     int ldo;
-    int ksplit;          // 1, or 4: four workgroups per tile each write an fp32 partial slab [ksplit][M][ldo] (EPI_F32 only)
+    int nw;              // waves = K segments per workgroup: 4 (qkv, gate/up, head) or 16 (o_proj, down_proj)
+    const uint16_t* ln_w;    // non-null: fold RMSNorm with this weight [1024] into the GEMM (K = 1024, nw = 4)
+    const int* row_index;    // optional gather: source row of X per GEMM row (speech head over the sampled rows)
 };
 
 // Host-side packing of a [N][K] bf16 matrix into MFMA-B-operand order:
@@ -32,10 +34,8 @@ void pack_weight(const uint16_t* W, int N, int K, int Npad, uint16_t* out);
 // gate/up interleave: packed tile 2t = gate tile t, 2t+1 = up tile t.
 void pack_gate_up(const uint16_t* Wg, const uint16_t* Wu, int Fdim, int K, uint16_t* out);
 
-int choose_mt(int M, int ntiles_x);
+int choose_mt(int M, int ntiles_x, int nw = 4, bool norm = false);
 hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s);
-// P (nullable): four fp32 slabs [4][Mrows][1024] of a ksplit=4 GEMM, folded and added to h (in place unless gather) before the norm
-hipError_t launch_add_rmsnorm(uint16_t* h, const float* P, int Mrows, const uint16_t* w, uint16_t* y, int rows, const int* gather, hipStream_t s);
 
 struct EmbedArgs {
     const int4* desc;          // per row {kind, a, b, c}

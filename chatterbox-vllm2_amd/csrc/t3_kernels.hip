@@ -74,18 +74,23 @@ __device__ __forceinline__ uint32_t silu_mul_bf(uint32_t g, uint32_t u) {   // b
 // ------------------------------------------------------------------------------------------------
 // Skinny GEMM  y[m][n] = sum_k x[m][k] * W[n][k]   (x, W bf16, fp32 accumulation on the matrix cores)
 //
-// Contract order (DESIGN.md "GEMM"): K is cut into 4 contiguous segments (one per wave of the
-// workgroup); a wave folds its segment with a chain of v_mfma_f32_16x16x32_bf16 in ascending k (each
+// Contract order (DESIGN.md "GEMM"): K is cut into NW contiguous segments (one per wave of the workgroup,
+// NW = 4 or 16); a wave folds its segment with a chain of v_mfma_f32_16x16x32_bf16 in ascending k (each
 // instruction folds 4 blocks of 8 consecutive k into the fp32 accumulator; its exact arithmetic was
-// identified on-device and is restated in the checker); the workgroup's result is the group sum
-// G = ((s0 + s1) + s2) + s3 in fp32.  With ksplit = 4 (o_proj, down_proj) four workgroups (blockIdx.z) each
-// write their G as an fp32 slab and the consumer (add_rmsnorm_kernel) folds ((G0 + G1) + G2) + G3.
+// identified on-device and is restated in the checker); four consecutive segments give a group sum
+// G = ((s0 + s1) + s2) + s3 in fp32; with 16 segments (o_proj, down_proj) the result is ((G0 + G1) + G2) + G3.
 //
-// One workgroup = 4 waves = NT n-tiles of 16 columns x MT m-tiles of 16 rows.  Weights are packed so
-// that a wave's weight load is one contiguous 1 KiB (pack_weight); activations are read row-major,
-// 16 rows x 64 B per wave instruction (L2-resident, they are tiny next to the weights).  Both operand
-// streams run through a PD-deep register ring: vmcnt retires in issue order, so the activation loads
-// must be issued as far ahead as the weight loads or they would drain the weight prefetch every step.
+// NORM form (qkv, gate/up, speech head; K = 1024, NW = 4): the RMSNorm that precedes the projection is
+// folded in -- the A operand is bf16(h * w_ln) formed in registers, the row statistic sum(h^2) is accumulated
+// from the very fragments the wave streams anyway, and the epilogue scales by rstd = 1/sqrt(ss/1024 + eps).
+// Statistic order: per wave (segment) and lane group q: sequential h*h adds over its 64 elements (kb outer, j
+// inner); butterfly over q (xor 16, xor 32); the four segment sums fold ((S0 + S1) + S2) + S3.
+//
+// One workgroup = NW waves = NT n-tiles of 16 columns x MT m-tiles of 16 rows.  Weights are packed so that a
+// wave's weight load is one contiguous 1 KiB (pack_weight); activations are read row-major, 16 rows x 64 B
+// per wave instruction (L2-resident, tiny next to the weights).  Both operand streams run through a PD-deep
+// register ring: vmcnt retires in issue order, so the activation loads must be issued as far ahead as the
+// weight loads or they would drain the weight prefetch every step.
 // ------------------------------------------------------------------------------------------------
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -96,13 +101,20 @@ __device__ __forceinline__ uint4 ld_nt(const uint4* p) {      // streamed-once d
 __device__ __forceinline__ bf16x8 as_frag(const uint4& v) {
     union { uint4 u; bf16x8 f; } c; c.u = v; return c.f;
 }
+// two fp32 -> packed bf16 pair, round-to-nearest-even (v_cvt_pk_bf16_f32; equals f2bf() for every non-NaN input)
+__device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    union { bf2 v; uint32_t u; } c;
+    c.v = (bf2){(__bf16)lo, (__bf16)hi};
+    return c.u;
+}
 
-template <int MT, int NT, int EPI, int PD>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][MT*NT][4 regs][64 lanes]
+template <int MT, int NT, int EPI, int PD, int NW, bool NORM>
+__global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [NW waves][MT*NT][4 regs][64 lanes] | NORM: [4][MT*16] row sums
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int KB = a.K >> 5, kbs = (KB >> 2) / (int)gridDim.z, kb0 = ((int)blockIdx.z * 4 + wave) * kbs;
+    const int KB = a.K >> 5, kbs = KB / NW, kb0 = wave * kbs;
 
     const uint4* wp[NT];
     const uint4* xp[MT];
@@ -112,28 +124,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     for (int i = 0; i < MT; ++i) {
         int m = (blockIdx.y * MT + i) * 16 + c;
         m = m < a.M ? m : a.M - 1;                 // padded rows re-read the last row; their outputs are dropped
+        if (a.row_index) m = a.row_index[m];
         xp[i] = reinterpret_cast<const uint4*>(a.X + (size_t)m * a.K + kb0 * 32 + q * 8);
     }
+    const uint4* lnp = NORM ? reinterpret_cast<const uint4*>(a.ln_w + kb0 * 32 + q * 8) : nullptr;
     f32x4 acc[MT][NT];
+    float ssq[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+        ssq[i] = 0.0f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
-    uint4 wr[PD][NT], xr[PD][MT];
+    uint4 wr[PD][NT], xr[PD][MT], lr[PD];
 #pragma unroll
     for (int j = 0; j < PD; ++j)
         if (j < kbs) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wr[j][t] = wp[t][j * 64];
+            for (int t = 0; t < NT; ++t) wr[j][t] = ld_nt(wp[t] + j * 64);
 #pragma unroll
             for (int i = 0; i < MT; ++i) xr[j][i] = xp[i][j * 4];
+            if (NORM) lr[j] = lnp[j * 4];
         }
     for (int kbase = 0; kbase < kbs; kbase += PD) {
 #pragma unroll
         for (int j = 0; j < PD; ++j) {
             const int kb = kbase + j;
             if (kb < kbs) {
+                if constexpr (NORM) {
+                    float lw[8]; unpack8(lr[j], lw);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        float xf[8]; unpack8(xr[j][i], xf);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ssq[i] = __builtin_fmaf(xf[e], xf[e], ssq[i]);
+                        uint4 o;
+                        o.x = cvt_pk(xf[0] * lw[0], xf[1] * lw[1]); o.y = cvt_pk(xf[2] * lw[2], xf[3] * lw[3]);
+                        o.z = cvt_pk(xf[4] * lw[4], xf[5] * lw[5]); o.w = cvt_pk(xf[6] * lw[6], xf[7] * lw[7]);
+                        xr[j][i] = o;
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -141,100 +172,150 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
                         acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(xr[j][i]), as_frag(wr[j][t]), acc[i][t], 0, 0, 0);
                 if (kb + PD < kbs) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) wr[j][t] = wp[t][(kb + PD) * 64];
+                    for (int t = 0; t < NT; ++t) wr[j][t] = ld_nt(wp[t] + (kb + PD) * 64);
 #pragma unroll
                     for (int i = 0; i < MT; ++i) xr[j][i] = xp[i][(kb + PD) * 4];
+                    if (NORM) lr[j] = lnp[(kb + PD) * 4];
                 }
             }
         }
     }
 
     // cross-wave (= cross-segment) reduction in segment order
+    float* rowsum = red + (size_t)NW * MT * NT * 256;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[((wave * (MT * NT) + i * NT + t) * 4 + r) * 64 + lane] = acc[i][t][r];
+    if constexpr (NORM) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float v = ssq[i];
+            v = v + __shfl_xor(v, 16); v = v + __shfl_xor(v, 32);
+            if (q == 0) rowsum[wave * (MT * 16) + i * 16 + c] = v;
+        }
+    }
     __syncthreads();
 
-    const int r = wave;                 // each wave finishes one accumulator register index
-    const int mrow = 4 * q + r, ncol = c;   // D[row = 4*(lane>>4) + reg][col = lane&15]
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m = (blockIdx.y * MT + i) * 16 + mrow;
-        float v[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int it = i * NT + t;
-            float s = red[((0 * (MT * NT) + it) * 4 + r) * 64 + lane];
-            s = s + red[((1 * (MT * NT) + it) * 4 + r) * 64 + lane];
-            s = s + red[((2 * (MT * NT) + it) * 4 + r) * 64 + lane];
-            s = s + red[((3 * (MT * NT) + it) * 4 + r) * 64 + lane];
-            v[t] = s;
-        }
+    // every thread finishes MT*NT*256 / (64*NW) outputs; D[row = 4*(lane>>4) + reg][col = lane&15]
+    constexpr int TOTAL = MT * NT * 256, STEP = NW * 64;
+    for (int idx = threadIdx.x; idx < TOTAL; idx += STEP) {
+        const int it = idx >> 8, r = (idx >> 6) & 3, l2 = idx & 63;
+        const int i = it / NT, t = it % NT;
+        const int m = (blockIdx.y * MT + i) * 16 + 4 * (l2 >> 4) + r;
         if (m >= a.M) continue;
-        if constexpr (EPI == EPI_SILU) {
-            static_assert(EPI != EPI_SILU || NT == 2, "SILU epilogue needs gate/up tile pairs");
-            const int n = blockIdx.x * 16 + ncol;      // tile pair index == output tile index
-            if (n < a.N)
-                reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)silu_mul_bf(f2bf(v[0]), f2bf(v[NT - 1]));
-        } else {
+        if (EPI == EPI_SILU && t != 0) continue;
+        float v[EPI == EPI_SILU ? 2 : 1];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int n = (blockIdx.x * NT + t) * 16 + ncol;
-                if (n >= a.N) continue;
-                if constexpr (EPI == EPI_F32) {     // blockIdx.z > 0: partial slab z of a split-K launch
-                    reinterpret_cast<float*>(a.out)[((size_t)blockIdx.z * a.M + m) * a.ldo + n] = v[t];
-                } else if constexpr (EPI == EPI_BF16) {
-                    reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)f2bf(v[t]);
-                } else {   // EPI_RESID: h = bf16(h + bf16(y))
-                    uint16_t* hp = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
-                    *hp = (uint16_t)f2bf(bf2f(*hp) + rbf(v[t]));
-                }
+        for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u) {
+            const int itu = it + u;
+            float tot = 0.0f;
+#pragma unroll
+            for (int gsum = 0; gsum < NW / 4; ++gsum) {
+                float s4 = red[(((4 * gsum + 0) * (MT * NT) + itu) * 4 + r) * 64 + l2];
+                s4 = s4 + red[(((4 * gsum + 1) * (MT * NT) + itu) * 4 + r) * 64 + l2];
+                s4 = s4 + red[(((4 * gsum + 2) * (MT * NT) + itu) * 4 + r) * 64 + l2];
+                s4 = s4 + red[(((4 * gsum + 3) * (MT * NT) + itu) * 4 + r) * 64 + l2];
+                tot = gsum == 0 ? s4 : tot + s4;
+            }
+            v[u] = tot;
+        }
+        if constexpr (NORM) {
+            const int rl = i * 16 + 4 * (l2 >> 4) + r;
+            const float ss = ((rowsum[rl] + rowsum[MT * 16 + rl]) + rowsum[2 * MT * 16 + rl]) + rowsum[3 * MT * 16 + rl];
+            const float rstd = 1.0f / sqrtf(ss * (1.0f / 1024.0f) + 1e-5f);
+#pragma unroll
+            for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u) v[u] = v[u] * rstd;
+        }
+        if constexpr (EPI == EPI_SILU) {
+            const int n = blockIdx.x * 16 + (l2 & 15);      // tile pair index == output tile index
+            if (n < a.N)
+                reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)silu_mul_bf(f2bf(v[0]), f2bf(v[1]));
+        } else {
+            const int n = (blockIdx.x * NT + t) * 16 + (l2 & 15);
+            if (n >= a.N) continue;
+            if constexpr (EPI == EPI_F32) {
+                reinterpret_cast<float*>(a.out)[(size_t)m * a.ldo + n] = v[0];
+            } else if constexpr (EPI == EPI_BF16) {
+                reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)f2bf(v[0]);
+            } else {   // EPI_RESID: h = bf16(h + bf16(y))
+                uint16_t* hp = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
+                *hp = (uint16_t)f2bf(bf2f(*hp) + rbf(v[0]));
             }
         }
     }
 }
 
-int choose_mt(int M, int ntiles_x) {
+int choose_mt(int M, int ntiles_x, int nw, bool norm) {
     const int mtiles = (M + 15) / 16;
     if (const char* e = getenv("T3_GEMM_MT")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) return v; }
-    // the weight tile should leave HBM once: let one workgroup cover all rows when it can (M <= 128)
-    (void)ntiles_x;
-    if (mtiles <= 1) return 1;
-    if (mtiles <= 2) return 2;
-    if (mtiles <= 4) return 4;
-    return 8;
+    // Largest row tile that (a) fits the register file (NORM form: 2 m-tiles; 16-wave form: 4) and (b) still launches
+    // >= 256 workgroups, one per CU.  Workgroups with the same blockIdx.x differ by a multiple of gridDim.x in linear
+    // id, and every gridDim.x used here is a multiple of 8, so they land on the same XCD and share the weight tile in L2.
+    const int cap = norm ? 2 : (nw == 16 ? 4 : 8);
+    int best = 1;
+    for (int mt = 1; mt <= cap; mt <<= 1) {
+        if (mt > 1 && mt / 2 >= mtiles) break;
+        const long wgs = (long)ntiles_x * ((mtiles + mt - 1) / mt);
+        if (mt == 1 || wgs >= 256) best = mt;
+    }
+    return best;
 }
 
-template <int MT, int NT, int EPI>
+template <int MT, int NT, int EPI, int NW, bool NORM>
 static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
-    constexpr int PD = (MT + NT) <= 3 ? 8 : (MT + NT) <= 6 ? 8 : 4;     // ring depth, bounded by the register file
+    // ring depth, bounded by the register file: 4-wave workgroups may use ~200 VGPRs, 16-wave ones 128
+    constexpr int PD = NW == 16 ? (MT <= 2 ? 4 : 2) : ((MT + NT) <= 6 ? 8 : 4);
     const int ntiles = (a.N + 15) / 16;           // EPI_SILU: N = F -> one workgroup per output tile (2 packed tiles)
     const int gx = (EPI == EPI_SILU) ? ntiles : (ntiles + NT - 1) / NT;
     const int gy = ((a.M + 15) / 16 + MT - 1) / MT;
-    const size_t lds = (size_t)4 * MT * NT * 4 * 64 * sizeof(float);
-    hipLaunchKernelGGL((gemm_kernel<MT, NT, EPI, PD>), dim3(gx, gy, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
+    const size_t lds = ((size_t)NW * MT * NT * 256 + (NORM ? 4 * MT * 16 : 0)) * sizeof(float);
+    auto kern = gemm_kernel<MT, NT, EPI, PD, NW, NORM>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NW * 64), lds, s, a);
     return hipGetLastError();
 }
 
+// epi: GemmEpi; nw: 4 (qkv / gate-up / head form) or 16 (o_proj / down_proj form); norm: fold RMSNorm (needs K = 1024, nw = 4)
 hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
-    const int ks = a.ksplit > 1 ? a.ksplit : 1;
-    if (a.K % (128 * ks) != 0 || (ks > 1 && epi != EPI_F32)) return hipErrorInvalidValue;
-#define T3_CASE(E, NT)                                                   \
-    switch (mt) {                                                        \
-        case 1: return launch_gemm_t<1, NT, E>(a, s);                    \
-        case 2: return launch_gemm_t<2, NT, E>(a, s);                    \
-        case 4: return launch_gemm_t<4, NT, E>(a, s);                    \
-        default: return launch_gemm_t<8 / NT, NT, E>(a, s);              \
+    const int nw = a.nw == 16 ? 16 : 4;
+    const bool norm = a.ln_w != nullptr;
+    if (a.K % (32 * nw) != 0 || (norm && (a.K != D || nw != 4))) return hipErrorInvalidValue;
+    if (nw == 16 && mt > 4) mt = 4;               // LDS: 16 waves x MT x 1 KiB x 4
+#define T3_CASE(E, NT, NWV, NRM)                                             \
+    switch (mt) {                                                            \
+        case 1: return launch_gemm_t<1, NT, E, NWV, NRM>(a, s);              \
+        case 2: return launch_gemm_t<2, NT, E, NWV, NRM>(a, s);              \
+        case 4: return launch_gemm_t<4, NT, E, NWV, NRM>(a, s);              \
+        default: return launch_gemm_t<(NWV == 16 ? 4 : 8 / NT), NT, E, NWV, NRM>(a, s); \
+    }
+    if (nw == 16) {
+        if (norm) return hipErrorInvalidValue;
+        switch (epi) {
+            case EPI_F32: T3_CASE(EPI_F32, 1, 16, false)
+            case EPI_RESID: T3_CASE(EPI_RESID, 1, 16, false)
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (norm) {
+        switch (epi) {
+            case EPI_F32: T3_CASE(EPI_F32, 1, 4, true)
+            case EPI_BF16: T3_CASE(EPI_BF16, 1, 4, true)
+            case EPI_SILU: T3_CASE(EPI_SILU, 2, 4, true)
+            default: return hipErrorInvalidValue;
+        }
     }
     switch (epi) {
-        case EPI_F32: T3_CASE(EPI_F32, 1)
-        case EPI_BF16: T3_CASE(EPI_BF16, 1)
-        case EPI_RESID: T3_CASE(EPI_RESID, 1)
-        case EPI_SILU: T3_CASE(EPI_SILU, 2)
+        case EPI_F32: T3_CASE(EPI_F32, 1, 4, false)
+        case EPI_BF16: T3_CASE(EPI_BF16, 1, 4, false)
+        case EPI_RESID: T3_CASE(EPI_RESID, 1, 4, false)
+        case EPI_SILU: T3_CASE(EPI_SILU, 2, 4, false)
     }
 #undef T3_CASE
     return hipErrorInvalidValue;
@@ -257,80 +338,6 @@ void pack_gate_up(const uint16_t* Wg, const uint16_t* Wu, int Fdim, int K, uint1
         pack_weight(Wg + (size_t)t * 16 * K, 16, K, 16, out + (size_t)(2 * t) * tile);
         pack_weight(Wu + (size_t)t * 16 * K, 16, K, 16, out + (size_t)(2 * t + 1) * tile);
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// (split-K fold + residual add +) RMSNorm: one wave per row of 1024.
-//   if P != null:  d = ((P0 + P1) + P2) + P3  (the four fp32 slabs of a ksplit=4 GEMM);  h = bf16(h + bf16(d))
-//   y = RMSNorm(h) * w
-// RMSNorm contract: lane l owns elements 8l..8l+7 then 512+8l..; sequential x*x adds; butterfly add over
-// xor 32,16,8,4,2,1; rstd = 1/sqrt(ss/1024 + eps); y = bf16(bf16(x*rstd) * w).
-// gather (optional): source row index per output row (h is then left untouched: the head only needs y).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fold4(const float* P, size_t slab, size_t off, float* d) {
-    const float4* p0 = reinterpret_cast<const float4*>(P + off);
-    const float4* p1 = reinterpret_cast<const float4*>(P + slab + off);
-    const float4* p2 = reinterpret_cast<const float4*>(P + 2 * slab + off);
-    const float4* p3 = reinterpret_cast<const float4*>(P + 3 * slab + off);
-#pragma unroll
-    for (int hlf = 0; hlf < 2; ++hlf) {
-        const float4 a = p0[hlf], b = p1[hlf], c = p2[hlf], e = p3[hlf];
-        d[4 * hlf + 0] = ((a.x + b.x) + c.x) + e.x; d[4 * hlf + 1] = ((a.y + b.y) + c.y) + e.y;
-        d[4 * hlf + 2] = ((a.z + b.z) + c.z) + e.z; d[4 * hlf + 3] = ((a.w + b.w) + c.w) + e.w;
-    }
-}
-__global__ __launch_bounds__(256) void add_rmsnorm_kernel(uint16_t* __restrict__ h, const float* __restrict__ P, int Mrows,
-                                                          const uint16_t* __restrict__ w, uint16_t* __restrict__ y, int rows,
-                                                          const int* __restrict__ gather) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int src = gather ? gather[row] : row;
-    uint4* xr = reinterpret_cast<uint4*>(h + (size_t)src * D);
-    const uint4* wr = reinterpret_cast<const uint4*>(w);
-    const uint4 va = xr[lane], vb = xr[64 + lane], wva = wr[lane], wvb = wr[64 + lane];
-    float fa[8], fb[8];
-    unpack8(va, fa); unpack8(vb, fb);
-    if (P) {
-        float da[8], db[8];
-        const size_t slab = (size_t)Mrows * D;
-        fold4(P, slab, (size_t)src * D + 8 * lane, da);
-        fold4(P, slab, (size_t)src * D + 512 + 8 * lane, db);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { fa[e] = rbf(fa[e] + rbf(da[e])); fb[e] = rbf(fb[e] + rbf(db[e])); }
-        if (!gather) {
-            uint4 na, nb;
-            na.x = pack2(fa[0], fa[1]); na.y = pack2(fa[2], fa[3]); na.z = pack2(fa[4], fa[5]); na.w = pack2(fa[6], fa[7]);
-            nb.x = pack2(fb[0], fb[1]); nb.y = pack2(fb[2], fb[3]); nb.z = pack2(fb[4], fb[5]); nb.w = pack2(fb[6], fb[7]);
-            xr[lane] = na; xr[64 + lane] = nb;
-        }
-    }
-    float ss = 0.0f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(fa[e], fa[e], ss);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(fb[e], fb[e], ss);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) ss = ss + __shfl_xor(ss, off);
-    const float rstd = 1.0f / sqrtf(ss * (1.0f / 1024.0f) + 1e-5f);
-    float wa[8], wb[8];
-    unpack8(wva, wa); unpack8(wvb, wb);
-    uint4 oa, ob;
-    oa.x = pack2(rbf(fa[0] * rstd) * wa[0], rbf(fa[1] * rstd) * wa[1]);
-    oa.y = pack2(rbf(fa[2] * rstd) * wa[2], rbf(fa[3] * rstd) * wa[3]);
-    oa.z = pack2(rbf(fa[4] * rstd) * wa[4], rbf(fa[5] * rstd) * wa[5]);
-    oa.w = pack2(rbf(fa[6] * rstd) * wa[6], rbf(fa[7] * rstd) * wa[7]);
-    ob.x = pack2(rbf(fb[0] * rstd) * wb[0], rbf(fb[1] * rstd) * wb[1]);
-    ob.y = pack2(rbf(fb[2] * rstd) * wb[2], rbf(fb[3] * rstd) * wb[3]);
-    ob.z = pack2(rbf(fb[4] * rstd) * wb[4], rbf(fb[5] * rstd) * wb[5]);
-    ob.w = pack2(rbf(fb[6] * rstd) * wb[6], rbf(fb[7] * rstd) * wb[7]);
-    uint4* yr = reinterpret_cast<uint4*>(y + (size_t)row * D);
-    yr[lane] = oa; yr[64 + lane] = ob;
-}
-
-hipError_t launch_add_rmsnorm(uint16_t* h, const float* P, int Mrows, const uint16_t* w, uint16_t* y, int rows, const int* gather, hipStream_t s) {
-    if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, P, Mrows, w, y, rows, gather);
-    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

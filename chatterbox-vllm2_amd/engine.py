@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "t3_create", "t3_destroy", "t3_last_error", "t3_load_tensor", "t3_finalize_weights", "t3_add_request",
     "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_release_request",
     "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_kernel_ms",
-    "t3k_gemm", "t3k_rmsnorm", "t3k_add_rmsnorm", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_sample", "t3k_expf",
+    "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_sample", "t3k_expf",
 ]
 
 KERNEL_CLASSES = ["gemm_qkv", "gemm_o", "gemm_gateup", "gemm_down", "gemm_head", "attention", "rmsnorm",
@@ -107,9 +107,9 @@ def load_library():
     L.t3_set_profile.argtypes = [vp, i32]
     L.t3_kernel_ms.argtypes = [vp, ct.c_char_p, ct.POINTER(ct.c_double), ct.POINTER(i64)]
     L.t3k_gemm.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32]
-    L.t3k_add_rmsnorm.argtypes = [vp, vp, vp, vp, i32]
-    L.t3k_rmsnorm.argtypes = [vp, vp, vp, i32]
-    L.t3k_silu_mul_gemm.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.t3k_norm_gemm.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32]
+    L.t3k_gemm_resid.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.t3k_silu_mul_gemm.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.t3k_rope_attention.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.t3k_sample.argtypes = [vp, i32, vp, ct.POINTER(T3Sampling), ct.c_float, ct.c_uint32, vp, vp]
     L.t3k_expf.argtypes = [vp, vp, i32]
@@ -263,35 +263,38 @@ def _bf(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
-def k_gemm(x: torch.Tensor, W: torch.Tensor, mt: int = 0, ksplit: int = 1) -> torch.Tensor:
-    """ksplit=1: four K-segments in one workgroup; ksplit=4: sixteen segments over four workgroups (o_proj/down_proj form)."""
+def k_gemm(x: torch.Tensor, W: torch.Tensor, mt: int = 0, nw: int = 4) -> torch.Tensor:
+    """nw = K segments per workgroup: 4 (qkv / gate-up / head form) or 16 (o_proj / down_proj form)."""
     x, W = _bf(x), _bf(W)
     M, K = x.shape; N = W.shape[0]
     out = torch.empty(M, N, dtype=torch.float32)
-    _chk_k(load_library().t3k_gemm(x.data_ptr(), W.data_ptr(), M, K, N, out.data_ptr(), mt, ksplit), "t3k_gemm")
+    _chk_k(load_library().t3k_gemm(x.data_ptr(), W.data_ptr(), M, K, N, out.data_ptr(), mt, nw), "t3k_gemm")
     return out
 
 
-def k_add_rmsnorm(h: torch.Tensor, P: torch.Tensor, w: torch.Tensor):
-    """h [rows,1024] bf16, P [4,rows,1024] fp32 -> (h_new, y)"""
-    h = _bf(h).clone(); w = _bf(w); P = P.to(torch.float32).contiguous()
-    y = torch.empty_like(h)
-    _chk_k(load_library().t3k_add_rmsnorm(h.data_ptr(), P.data_ptr(), w.data_ptr(), y.data_ptr(), h.shape[0]), "t3k_add_rmsnorm")
-    return h, y
+def k_norm_gemm(h: torch.Tensor, ln_w: torch.Tensor, W: torch.Tensor, row_index=None) -> torch.Tensor:
+    """RMSNorm folded into the projection; optional gather of rows of h."""
+    h, ln_w, W = _bf(h), _bf(ln_w), _bf(W)
+    ri = None if row_index is None else np.ascontiguousarray(np.asarray(row_index, dtype=np.int32))
+    M = h.shape[0] if ri is None else len(ri)
+    out = torch.empty(M, W.shape[0], dtype=torch.float32)
+    _chk_k(load_library().t3k_norm_gemm(h.data_ptr(), ln_w.data_ptr(), W.data_ptr(), M, W.shape[0], out.data_ptr(),
+                                        None if ri is None else ri.ctypes.data, h.shape[0]), "t3k_norm_gemm")
+    return out
 
 
-def k_rmsnorm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    x, w = _bf(x), _bf(w)
-    y = torch.empty_like(x)
-    _chk_k(load_library().t3k_rmsnorm(x.data_ptr(), w.data_ptr(), y.data_ptr(), x.shape[0]), "t3k_rmsnorm")
-    return y
+def k_gemm_resid(x: torch.Tensor, W: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+    """returns bf16(h + bf16(x W^T)) computed by the o_proj / down_proj form."""
+    x, W = _bf(x), _bf(W); h = _bf(h).clone()
+    _chk_k(load_library().t3k_gemm_resid(x.data_ptr(), W.data_ptr(), x.shape[0], x.shape[1], W.shape[0], h.data_ptr()), "t3k_gemm_resid")
+    return h
 
 
-def k_silu_mul_gemm(x: torch.Tensor, Wg: torch.Tensor, Wu: torch.Tensor) -> torch.Tensor:
-    x, Wg, Wu = _bf(x), _bf(Wg), _bf(Wu)
-    M, Fd = x.shape[0], Wg.shape[0]
+def k_silu_mul_gemm(h: torch.Tensor, ln_w: torch.Tensor, Wg: torch.Tensor, Wu: torch.Tensor) -> torch.Tensor:
+    h, ln_w, Wg, Wu = _bf(h), _bf(ln_w), _bf(Wg), _bf(Wu)
+    M, Fd = h.shape[0], Wg.shape[0]
     out = torch.empty(M, Fd, dtype=torch.bfloat16)
-    _chk_k(load_library().t3k_silu_mul_gemm(x.data_ptr(), Wg.data_ptr(), Wu.data_ptr(), M, Fd, out.data_ptr()), "t3k_silu_mul_gemm")
+    _chk_k(load_library().t3k_silu_mul_gemm(h.data_ptr(), ln_w.data_ptr(), Wg.data_ptr(), Wu.data_ptr(), M, Fd, out.data_ptr()), "t3k_silu_mul_gemm")
     return out
 
 

@@ -135,18 +135,22 @@ int t3_stats(T3Handle h, T3Stats* out);
 int t3_reset_stats(T3Handle h);
 /* Average duration (ms) per launch of each kernel class over decode-only steps since the last reset,
  * measured with HIP events on the engine's stream when profiling is on (t3_set_profile).
- * names: "gemm_qkv","gemm_o","gemm_gateup","gemm_down","gemm_head","attention","rmsnorm","rope_kv","embed","sampler". */
+ * names: "gemm_qkv","gemm_o","gemm_gateup","gemm_down","gemm_head","attention","rmsnorm" (unused: folded),"rope_kv","embed","sampler". */
 int t3_set_profile(T3Handle h, int32_t on);
 int t3_kernel_ms(T3Handle h, const char* name, double* avg_ms, int64_t* launches);
 
 /* ---- kernel-level entry points (host buffers in, host buffers out; used by the parity tests) ----
  * Each runs exactly the kernel the engine uses, on the current device, and waits for it.      */
 int t3k_gemm(const void* x_bf16 /*[M][K]*/, const void* w_bf16 /*[N][K]*/, int32_t M, int32_t K, int32_t N,
-             float* out_f32 /*[M][N]*/, int32_t mt /*0 = auto*/, int32_t ksplit /*1, or 4 = o_proj/down_proj form*/);
-int t3k_rmsnorm(const void* x_bf16, const void* w_bf16, void* y_bf16, int32_t rows);
-/* split-K fold + residual add + RMSNorm: h [rows][1024] bf16 (updated in place), P [4][rows][1024] fp32 slabs */
-int t3k_add_rmsnorm(void* h_bf16, const float* P_f32, const void* w_bf16, void* y_bf16, int32_t rows);
-int t3k_silu_mul_gemm(const void* x_bf16 /*[M][1024]*/, const void* wg_bf16 /*[F][1024]*/, const void* wu_bf16,
+             float* out_f32 /*[M][N]*/, int32_t mt /*0 = auto*/, int32_t nw /*K segments: 4, or 16 = o_proj/down_proj form*/);
+/* RMSNorm folded into the projection (qkv / gate-up / speech-head form): out[r] = rstd * GEMM(bf16(h[row_index[r]] * ln_w), W);
+ * h [Mh][1024] bf16, row_index nullable (then M == Mh). */
+int t3k_norm_gemm(const void* h_bf16, const void* ln_w_bf16, const void* w_bf16 /*[N][1024]*/, int32_t M, int32_t N,
+                  float* out_f32, const int32_t* row_index, int32_t Mh);
+/* residual epilogue (o_proj / down_proj form, 16 K-segments): h [M][N] bf16 updated in place, h = bf16(h + bf16(x W^T)) */
+int t3k_gemm_resid(const void* x_bf16, const void* w_bf16, int32_t M, int32_t K, int32_t N, void* h_bf16);
+/* gate/up form with folded RMSNorm and SiLU*mul epilogue */
+int t3k_silu_mul_gemm(const void* h_bf16 /*[M][1024]*/, const void* ln_w_bf16, const void* wg_bf16 /*[F][1024]*/, const void* wu_bf16,
                       int32_t M, int32_t F, void* out_bf16 /*[M][F]*/);
 /* RoPE + paged-KV write + paged attention for `rows` rows of ONE layer over a scratch pool:
  * qkv [rows][3072] bf16 (pre-RoPE), row_stream/row_pos int32 [rows]; rows are processed in the given

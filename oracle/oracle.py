@@ -68,6 +68,8 @@ def lib():
         L.orc_expf.restype = f32; L.orc_expf.argtypes = [f32]
         L.orc_gemm_nk.argtypes = [vp, vp, i32, i32, i32, vp, i32]
         L.orc_rmsnorm.argtypes = [vp, vp, vp, i32]
+        L.orc_norm_gemm_nk.argtypes = [vp, vp, vp, i32, i32, vp]
+        L.orc_row_rstd.argtypes = [vp, i32, vp]
         L.orc_rope_table.argtypes = [i32, vp, vp]
         L.orc_rope.argtypes = [vp, vp, i32, vp, vp]
         L.orc_attn_row.argtypes = [vp, vp, vp, i32, i32, vp]
@@ -110,6 +112,20 @@ def gemm(x: torch.Tensor, W: torch.Tensor, seg_len: int = 0) -> torch.Tensor:
     assert K % seg_len == 0 and K // seg_len in (4, 16) and seg_len % 32 == 0
     out = torch.empty(M, N, dtype=torch.float32)
     lib().orc_gemm_nk(_p(x), _p(W), M, K, N, _p(out), seg_len)
+    return out
+
+
+def norm_gemm(h: torch.Tensor, w: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    """RMSNorm folded into the GEMM: rstd[m] * GEMM(bf16(h*w), W); h [M,1024], w [1024], W [N,1024] bf16 -> fp32 [M,N]."""
+    h, w, W = _bf(h), _bf(w), _bf(W)
+    out = torch.empty(h.shape[0], W.shape[0], dtype=torch.float32)
+    lib().orc_norm_gemm_nk(_p(h), _p(w), _p(W), h.shape[0], W.shape[0], _p(out))
+    return out
+
+
+def row_rstd(h: torch.Tensor) -> torch.Tensor:
+    h = _bf(h); out = torch.empty(h.shape[0], dtype=torch.float32)
+    lib().orc_row_rstd(_p(h), h.shape[0], _p(out))
     return out
 
 

@@ -223,6 +223,46 @@ void orc_gemm_w(const uint16_t* x, const OrcW* W, int M, float* out, int seg_len
         }
 }
 
+/* RMSNorm folded into the consuming GEMM (DESIGN.md "RMSNorm"):  y = rstd[m] * GEMM(bf16(h (.) w), W).
+ * Row statistic, in the order the GEMM waves see the operand: segment s = k / 256 (one wave), lane group
+ * q = (k % 32) / 8; p_q = sequential h*h adds over kb = 0..7 (k = 256 s + 32 kb + 8 q + j, j = 0..7 inner);
+ * S_s = (p_0 + p_1) + (p_2 + p_3);  ss = ((S_0 + S_1) + S_2) + S_3;  rstd = 1 / sqrt(ss / 1024 + eps).   */
+void orc_row_rstd(const uint16_t* h, int rows, float* rstd) {
+    for (int r = 0; r < rows; ++r) {
+        const uint16_t* x = h + (size_t)r * T3_D;
+        float S[4];
+        for (int s = 0; s < 4; ++s) {
+            float p[4];
+            for (int q = 0; q < 4; ++q) {
+                float a = 0.0f;
+                for (int kb = 0; kb < 8; ++kb)
+                    for (int j = 0; j < 8; ++j) { const float v = bf2f(x[256 * s + 32 * kb + 8 * q + j]); a = fmaf(v, v, a); }
+                p[q] = a;
+            }
+            S[s] = (p[0] + p[1]) + (p[2] + p[3]);
+        }
+        const float ss = ((S[0] + S[1]) + S[2]) + S[3];
+        rstd[r] = 1.0f / sqrtf(ss * (1.0f / 1024.0f) + T3_EPS);
+    }
+}
+/* out[m][n] = rstd[m] * GEMM(bf16(h[m][k] * w[k]), W)   (K = 1024, segments of 256) */
+void orc_norm_gemm_w(const uint16_t* h, const uint16_t* w, const OrcW* W, int M, float* out) {
+    uint16_t* xw = (uint16_t*)malloc((size_t)M * T3_D * 2);
+    float* rstd = (float*)malloc(sizeof(float) * M);
+    for (int m = 0; m < M; ++m)
+        for (int k = 0; k < T3_D; ++k) xw[(size_t)m * T3_D + k] = f2bf(bf2f(h[(size_t)m * T3_D + k]) * bf2f(w[k]));
+    orc_row_rstd(h, M, rstd);
+    orc_gemm_w(xw, W, M, out, 256);
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < W->N; ++n) out[(size_t)m * W->N + n] = out[(size_t)m * W->N + n] * rstd[m];
+    free(xw); free(rstd);
+}
+void orc_norm_gemm_nk(const uint16_t* h, const uint16_t* w, const uint16_t* Wn, int M, int N, float* out) {
+    OrcW W = orcw_make(Wn, N, T3_D);
+    orc_norm_gemm_w(h, w, &W, M, out);
+    orcw_free(&W);
+}
+
 /* Helper for tests: W given in its natural [N][K] layout. */
 void orc_gemm_nk(const uint16_t* x, const uint16_t* W, int M, int K, int N, float* out, int seg_len) {
     OrcW w = orcw_make(W, N, K);
@@ -239,7 +279,9 @@ static void bfly_add(float v[64], const int* offs, int n) {
     }
 }
 
-/* ------------------------------------------------------------------ RMSNorm
+/* ------------------------------------------------------------------ RMSNorm (stand-alone form)
+ * NOT on the model path any more (the path folds the norm into the consuming GEMM, orc_norm_gemm_w); kept as the
+ * restatement of the stand-alone kernel the C ABI still exports (t3k_rmsnorm).
  * One row of 1024 bf16.  Lane l (0..63) owns elements 8l..8l+7 then 512+8l..512+8l+7,
  * ss_l = sequential x*x adds; butterfly add over xor 32,16,8,4,2,1;
  * rstd = 1/sqrt(ss/1024 + eps) (IEEE sqrt, IEEE divide);
@@ -495,7 +537,6 @@ static inline uint16_t* kv_at(OrcModel* m, int stream, int layer, int pos) {
  * If tap_layer >= 0, the residual stream after that many layers is copied to tap.                */
 void orc_forward_rows(OrcModel* m, uint16_t* h, const int* row_stream, const int* row_pos, int rows,
                       int tap_layer, uint16_t* tap) {
-    uint16_t* xn = (uint16_t*)malloc((size_t)rows * T3_D * 2);
     float* f = (float*)malloc((size_t)rows * 8192 * sizeof(float));
     uint16_t* qkv = (uint16_t*)malloc((size_t)rows * 3072 * 2);
     uint16_t* att = (uint16_t*)malloc((size_t)rows * T3_D * 2);
@@ -503,8 +544,7 @@ void orc_forward_rows(OrcModel* m, uint16_t* h, const int* row_stream, const int
     for (int L = 0; L < m->n_layers; ++L) {
         if (tap_layer == L && tap) memcpy(tap, h, (size_t)rows * T3_D * 2);
         OrcLayer* y = &m->layers[L];
-        orc_rmsnorm(h, y->ln1, xn, rows);
-        orc_gemm_w(xn, &y->wqkv, rows, f, 256);
+        orc_norm_gemm_w(h, y->ln1, &y->wqkv, rows, f);
         for (size_t i = 0; i < (size_t)rows * 3072; ++i) qkv[i] = f2bf(f[i]);
         for (int r = 0; r < rows; ++r) {
             uint16_t* q = qkv + (size_t)r * 3072;
@@ -522,8 +562,7 @@ void orc_forward_rows(OrcModel* m, uint16_t* h, const int* row_stream, const int
             }
         orc_gemm_w(att, &y->wo, rows, f, 64);
         for (size_t i = 0; i < (size_t)rows * T3_D; ++i) h[i] = f2bf(bf2f(h[i]) + rbf(f[i]));
-        orc_rmsnorm(h, y->ln2, xn, rows);
-        orc_gemm_w(xn, &y->wgu, rows, f, 256);
+        orc_norm_gemm_w(h, y->ln2, &y->wgu, rows, f);
         for (int r = 0; r < rows; ++r)
             for (int i = 0; i < T3_F; ++i)
                 act[(size_t)r * T3_F + i] = silu_mul(f2bf(f[(size_t)r * 8192 + i]), f2bf(f[(size_t)r * 8192 + 4096 + i]));
@@ -531,7 +570,7 @@ void orc_forward_rows(OrcModel* m, uint16_t* h, const int* row_stream, const int
         for (size_t i = 0; i < (size_t)rows * T3_D; ++i) h[i] = f2bf(bf2f(h[i]) + rbf(f[i]));
     }
     if (tap_layer == m->n_layers && tap) memcpy(tap, h, (size_t)rows * T3_D * 2);
-    free(xn); free(f); free(qkv); free(att); free(act);
+    free(f); free(qkv); free(att); free(act);
 }
 
 /* final norm + speech head + CFG for one utterance.  hc/hu: residual rows of the cond / uncond
@@ -539,11 +578,10 @@ void orc_forward_rows(OrcModel* m, uint16_t* h, const int* row_stream, const int
  * d = bf16(lc - lu); e = bf16(cfg * d); l = bf16(lc + e).                                        */
 void orc_cfg_logits(OrcModel* m, const uint16_t* hc, const uint16_t* hu, float cfg, float* out,
                     float* out_cond, float* out_uncond) {
-    uint16_t x[2 * T3_D], xn[2 * T3_D];
+    uint16_t x[2 * T3_D];
     memcpy(x, hc, T3_D * 2); memcpy(x + T3_D, hu, T3_D * 2);
-    orc_rmsnorm(x, m->norm, xn, 2);
     float* f = (float*)malloc(sizeof(float) * 2 * T3_V);
-    orc_gemm_w(xn, &m->head, 2, f, 256);
+    orc_norm_gemm_w(x, m->norm, &m->head, 2, f);
     for (int v = 0; v < T3_V; ++v) {
         const float lc = rbf(f[v]), lu = rbf(f[T3_V + v]);
         const float d = rbf(lc - lu);

@@ -42,22 +42,36 @@ def test_gemm_bit_exact(E, oracle, M, K, N, mt):
     assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("M,K,N,mt", [(64, 1024, 1024, 0), (64, 4096, 1024, 0), (3, 4096, 48, 1), (130, 1024, 64, 8), (16, 512, 32, 0)])
-def test_gemm_split4_bit_exact(E, oracle, M, K, N, mt):
-    """o_proj / down_proj form: 16 segments of K/16 over four workgroups, slabs folded ((G0+G1)+G2)+G3."""
+@pytest.mark.parametrize("M,K,N,mt", [(64, 1024, 1024, 0), (64, 4096, 1024, 0), (3, 4096, 48, 1), (130, 1024, 64, 4), (16, 512, 32, 0), (2, 1024, 1024, 0)])
+def test_gemm_16_segments_bit_exact(E, oracle, M, K, N, mt):
+    """o_proj / down_proj form: 16 K-segments (16 waves) in one workgroup, groups of four folded ((G0+G1)+G2)+G3."""
     x = rand_bf16(M, K, seed=M + K + 1); W = rand_bf16(N, K, seed=N + 1, scale=0.05)
-    assert_bit_equal(E.k_gemm(x, W, mt, ksplit=4), oracle.gemm(x, W, K // 16), f"split-K gemm {M}x{K}x{N}")
+    assert_bit_equal(E.k_gemm(x, W, mt, nw=16), oracle.gemm(x, W, K // 16), f"16-segment gemm {M}x{K}x{N}")
 
 
-def test_add_rmsnorm_bit_exact(E, oracle):
-    rows = 37
-    h = rand_bf16(rows, 1024, seed=1, scale=2.0); w = (rand_bf16(1024, seed=2) + 1.0).to(torch.bfloat16)
-    P = torch.randn(4, rows, 1024, generator=torch.Generator().manual_seed(3))
-    d = (((P[0] + P[1]) + P[2]) + P[3]).to(torch.bfloat16)
-    want_h = (h.float() + d.float()).to(torch.bfloat16)
-    got_h, got_y = E.k_add_rmsnorm(h, P, w)
-    assert_bit_equal(got_h, want_h, "residual add")
-    assert_bit_equal(got_y, oracle.rmsnorm(want_h, w), "rmsnorm after add")
+@pytest.mark.parametrize("M,K", [(64, 1024), (5, 4096), (40, 4096)])
+def test_gemm_residual_epilogue_bit_exact(E, oracle, M, K):
+    x = rand_bf16(M, K, seed=3); W = rand_bf16(1024, K, seed=4, scale=0.05); h = rand_bf16(M, 1024, seed=5, scale=2.0)
+    y = oracle.gemm(x, W, K // 16).to(torch.bfloat16)
+    want = (h.float() + y.float()).to(torch.bfloat16)
+    assert_bit_equal(E.k_gemm_resid(x, W, h), want, "h + bf16(x W^T)")
+
+
+@pytest.mark.parametrize("M,N", [(2, 3072), (64, 3072), (37, 8194), (200, 64)])
+def test_norm_folded_gemm_bit_exact(E, oracle, M, N):
+    """RMSNorm folded into the projection: rstd * GEMM(bf16(h * w_ln), W), statistic accumulated from the operand stream."""
+    h = rand_bf16(M, 1024, seed=M, scale=3.0); ln = (rand_bf16(1024, seed=9) + 1.0).to(torch.bfloat16); W = rand_bf16(N, 1024, seed=N, scale=0.05)
+    got = E.k_norm_gemm(h, ln, W)
+    assert_bit_equal(got, oracle.norm_gemm(h, ln, W), f"norm+gemm {M}x{N}")
+    # against the textbook formula in fp64 (tolerance: bf16 operand rounding)
+    hd = h.double(); ref = (hd * torch.rsqrt(hd.pow(2).mean(-1, keepdim=True) + 1e-5) * ln.double()) @ W.double().T
+    assert (got.double() - ref).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
+
+
+def test_norm_folded_gemm_row_gather(E, oracle):
+    h = rand_bf16(50, 1024, seed=1, scale=2.0); ln = (rand_bf16(1024, seed=2) + 1.0).to(torch.bfloat16); W = rand_bf16(160, 1024, seed=3, scale=0.05)
+    idx = [49, 0, 7, 7, 31, 12]
+    assert_bit_equal(E.k_norm_gemm(h, ln, W, row_index=idx), oracle.norm_gemm(h[idx], ln, W), "gathered rows (speech-head form)")
 
 
 def test_gemm_wide_dynamic_range(E, oracle):
@@ -67,20 +81,14 @@ def test_gemm_wide_dynamic_range(E, oracle):
     assert_bit_equal(E.k_gemm(x, W), oracle.gemm(x, W), "gemm wide range")
 
 
-@pytest.mark.parametrize("rows", [1, 3, 64, 257])
-def test_rmsnorm_bit_exact(E, oracle, rows):
-    x = rand_bf16(rows, 1024, seed=rows, scale=3.0); w = rand_bf16(1024, seed=9) + 1.0
-    w = w.to(torch.bfloat16)
-    assert_bit_equal(E.k_rmsnorm(x, w), oracle.rmsnorm(x, w), "rmsnorm")
-
-
 @pytest.mark.parametrize("M", [2, 40])
 def test_gate_up_silu_bit_exact(E, oracle, M):
     Fd = 512
-    x = rand_bf16(M, 1024, seed=1); Wg = rand_bf16(Fd, 1024, seed=2, scale=0.1); Wu = rand_bf16(Fd, 1024, seed=3, scale=0.1)
-    got = E.k_silu_mul_gemm(x, Wg, Wu)
-    g = oracle.gemm(x, Wg).to(torch.bfloat16); u = oracle.gemm(x, Wu).to(torch.bfloat16)
-    assert_bit_equal(got, oracle.silu_mul(g, u), "silu(gate)*up")
+    h = rand_bf16(M, 1024, seed=1, scale=2.0); ln = (rand_bf16(1024, seed=8) + 1.0).to(torch.bfloat16)
+    Wg = rand_bf16(Fd, 1024, seed=2, scale=0.1); Wu = rand_bf16(Fd, 1024, seed=3, scale=0.1)
+    got = E.k_silu_mul_gemm(h, ln, Wg, Wu)
+    g = oracle.norm_gemm(h, ln, Wg).to(torch.bfloat16); u = oracle.norm_gemm(h, ln, Wu).to(torch.bfloat16)
+    assert_bit_equal(got, oracle.silu_mul(g, u), "silu(gate)*up with folded norm")
 
 
 def _oracle_rope_attention(oracle, qkv, row_stream, row_pos, n_streams, max_pos):

@@ -94,7 +94,8 @@ def test_oracle_vs_transformers_llama(oracle, n_layers):
     ec, _ = m.prompt_embeds(prompt, synthetic_cond_emb(1))
     T = len(prompt)
     h, _ = m.forward_rows(ec, [0] * T, list(range(T)))
-    got = oracle.rmsnorm(h, dict(tens)["tfmr.norm.weight"]).float()
+    hf32 = h.float()                     # final RMSNorm in plain fp32 here: the path folds it into the head GEMM
+    got = hf32 * torch.rsqrt(hf32.pow(2).mean(-1, keepdim=True) + 1e-5) * dict(tens)["tfmr.norm.weight"].float()
     with torch.no_grad():
         ref32 = _hf_model(tens, n_layers, torch.float32)(inputs_embeds=ec.float()[None]).last_hidden_state[0]
         ref16 = _hf_model(tens, n_layers, torch.bfloat16)(inputs_embeds=ec[None]).last_hidden_state[0].float()
@@ -103,6 +104,16 @@ def test_oracle_vs_transformers_llama(oracle, n_layers):
     cos = torch.nn.functional.cosine_similarity(got.flatten(), ref32.flatten(), dim=0).item()
     assert cos > 0.9995, cos
     assert err_oracle < 1.5 * err_hf_bf16 + 1e-4, (err_oracle, err_hf_bf16)
+
+
+def test_norm_folded_gemm_matches_textbook(oracle):
+    g = torch.Generator().manual_seed(3)
+    h = (torch.randn(6, 1024, generator=g) * 4).to(torch.bfloat16); ln = (torch.randn(1024, generator=g) * 0.1 + 1).to(torch.bfloat16)
+    W = (torch.randn(33, 1024, generator=g) * 0.05).to(torch.bfloat16)
+    hd = h.double(); ref = (hd * torch.rsqrt(hd.pow(2).mean(-1, keepdim=True) + 1e-5) * ln.double()) @ W.double().T
+    got = oracle.norm_gemm(h, ln, W).double()
+    assert (got - ref).abs().max().item() < 0.02 * ref.abs().max().item()
+    assert torch.allclose(oracle.row_rstd(h).double(), torch.rsqrt(hd.pow(2).mean(-1) + 1e-5), rtol=1e-6)
 
 
 def test_gemm_matches_fp32_matmul(oracle):
