@@ -393,6 +393,22 @@ __device__ __forceinline__ void rope8(const uint4& x1, const uint4& x2, const fl
     o1.x = pack2(r1[0], r1[1]); o1.y = pack2(r1[2], r1[3]); o1.z = pack2(r1[4], r1[5]); o1.w = pack2(r1[6], r1[7]);
     o2.x = pack2(r2[0], r2[1]); o2.y = pack2(r2[2], r2[3]); o2.z = pack2(r2[4], r2[5]); o2.w = pack2(r2[6], r2[7]);
 }
+// Paged KV layout of one (block, head): [chunk-in-block (KV_BLOCK/64)][8 fragments][64 lanes][8 bf16] for K and for V.
+//   K fragment (tt, ds), lane t + 16 kg, element j  =  K[token 16 tt + t of the chunk][dim 32 ds + 8 kg + j]    (MFMA A operand: rows = tokens)
+//   V fragment (dt, ts), lane d + 16 kg, element j  =  V[token 32 ts + 8 kg + j of the chunk][dim 16 dt + d]    (MFMA A operand: rows = dims)
+// so the attention kernel feeds v_mfma_f32_16x16x32_bf16 straight from fully coalesced 1 KiB wave loads.
+__device__ __forceinline__ size_t kv_head_base(int blk, int kv, int h) {
+    return (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(kv * H + h) * KV_BLOCK) * HD;
+}
+__device__ __forceinline__ size_t k_slot(int tok_in_block, int ds, int kg) {      // start of the 8-element (16 B) piece
+    const int ci = tok_in_block / CHUNK, tc = tok_in_block % CHUNK;
+    return (size_t)ci * (CHUNK * HD) + (size_t)((tc >> 4) * 2 + ds) * 512 + (size_t)((tc & 15) + 16 * kg) * 8;
+}
+__device__ __forceinline__ size_t v_elem(int tok_in_block, int dim) {              // one bf16
+    const int ci = tok_in_block / CHUNK, tc = tok_in_block % CHUNK;
+    return (size_t)ci * (CHUNK * HD) + (size_t)((dim >> 4) * 2 + (tc >> 5)) * 512 + (size_t)((dim & 15) + 16 * ((tc & 31) >> 3)) * 8 + (tc & 7);
+}
+
 __global__ __launch_bounds__(256) void rope_kv_kernel(RopeArgs a) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
@@ -413,12 +429,13 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(RopeArgs a) {
     uint16_t* qo = a.q_out + (size_t)row * D + h * 64;
     *reinterpret_cast<uint4*>(qo + i0) = o1; *reinterpret_cast<uint4*>(qo + 32 + i0) = o2;
     rope8(*reinterpret_cast<const uint4*>(qr + D + h * 64 + i0), *reinterpret_cast<const uint4*>(qr + D + h * 64 + 32 + i0), c, s, o1, o2);
-    uint16_t* kb = a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(0 * H + h) * KV_BLOCK + tok) * HD;
-    *reinterpret_cast<uint4*>(kb + i0) = o1; *reinterpret_cast<uint4*>(kb + 32 + i0) = o2;
-    uint16_t* vb = a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(1 * H + h) * KV_BLOCK + tok) * HD;
-    const uint4* vs = reinterpret_cast<const uint4*>(qr + 2 * D + h * 64 + part * 16);
-    reinterpret_cast<uint4*>(vb + part * 16)[0] = vs[0];
-    reinterpret_cast<uint4*>(vb + part * 16)[1] = vs[1];
+    uint16_t* kb = a.kv_layer + kv_head_base(blk, 0, h);
+    *reinterpret_cast<uint4*>(kb + k_slot(tok, 0, part)) = o1;       // dims 8*part..   -> ds 0, kg = part
+    *reinterpret_cast<uint4*>(kb + k_slot(tok, 1, part)) = o2;       // dims 32+8*part.. -> ds 1, kg = part
+    uint16_t* vb = a.kv_layer + kv_head_base(blk, 1, h);
+    const uint16_t* vs = qr + 2 * D + h * 64 + part * 16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) vb[v_elem(tok, part * 16 + e)] = vs[e];
 }
 hipError_t launch_rope_kv(const RopeArgs& a, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
@@ -428,130 +445,149 @@ hipError_t launch_rope_kv(const RopeArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------
 // Paged attention for one (row, head): context = positions 0..row_pos of the row's stream.
-// One workgroup of 4 waves; wave w takes chunks c = w, w+4, ... (chunk = one 64-token KV block of
-// this head = 8 KiB K + 8 KiB V, contiguous, read with fully coalesced 1 KiB wave loads straight to
-// VGPRs).  lane = 8*g + e8: token 8i+g of the chunk (i = 0..7), dims 8*e8..8*e8+7.
-// Per-chunk (m_c, l_c, o_c[64]) go to LDS; wave 0 combines them in ascending chunk order.
+// One workgroup of NW waves; wave w takes chunks c = w, w+NW, ... (chunk = 64 tokens = 8 KiB K + 8 KiB V of this head,
+// contiguous, read with fully coalesced 1 KiB wave loads straight into MFMA operand registers).
+// QK^T and P.V run on the matrix cores (v_mfma_f32_16x16x32_bf16; q and the bf16 probabilities are replicated over
+// the 16 B-operand columns, so every column of D carries the same numbers); the softmax needs ONE exp per lane
+// (lane = token).  Per-chunk (m_c, l_c, o_c[64]) go to LDS; wave 0 folds them in ascending chunk order.
 // All orders are the contract's (DESIGN.md "Attention").
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void patch16(uint4& v, int j, uint32_t val) {      // replace bf16 element j (0..7) of v
+    const uint32_t sh = (j & 1) * 16, keep = ~(0xffffu << sh), ins = val << sh;
+    const int w = j >> 1;
+    v.x = w == 0 ? ((v.x & keep) | ins) : v.x; v.y = w == 1 ? ((v.y & keep) | ins) : v.y;
+    v.z = w == 2 ? ((v.z & keep) | ins) : v.z; v.w = w == 3 ? ((v.w & keep) | ins) : v.w;
+}
+
 template <int NW, bool NT, bool FUSE>
 __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float part[];   // [max_chunks] m | [max_chunks] l | [max_chunks][64] o
+    extern __shared__ __attribute__((aligned(16))) float part[];   // [max_chunks] m | [max_chunks] l | [max_chunks][64] o | per wave: 64 scores, 64 bf16 p
     float* pm = part; float* pl = part + a.max_chunks; float* po = part + 2 * a.max_chunks;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* sbuf = part + 66 * a.max_chunks + wave * 96;            // 64 floats of scores, then 64 bf16 (32 floats) of probabilities
+    uint16_t* pbuf = reinterpret_cast<uint16_t*>(sbuf + 64);
     const int h = blockIdx.x, row = blockIdx.y;
     const int stream = a.row_stream[row], L = a.row_pos[row] + 1;
     const int nc = (L + CHUNK - 1) / CHUNK;
-    const int g = lane >> 3, e8 = lane & 7;
-    float qf[8];
+    const int col = lane & 15, kg = lane >> 4;
     const int* bt = a.block_table + (size_t)stream * a.max_blocks;
     constexpr int CPB = KV_BLOCK / CHUNK;          // chunks per physical block
+
+    uint4 kf[8], vf[8];                            // K fragments (tt, ds) at 2 tt + ds; V fragments (dt, ts) at 2 dt + ts
+    auto load_tiles = [&](int c) {
+        const int blk = bt[c / CPB], ci = c % CPB;
+        const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 0, h) + (size_t)ci * (CHUNK * HD)) + lane;
+        const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 1, h) + (size_t)ci * (CHUNK * HD)) + lane;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) kf[f] = NT ? ld_nt(Kp + f * 64) : Kp[f * 64];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) vf[f] = NT ? ld_nt(Vp + f * 64) : Vp[f * 64];
+    };
     // the wave's first K/V tile is requested before anything else so that the q / RoPE prologue overlaps its flight
-    uint4 kk[8], vv[8];
-    if (wave < nc) {
-        const int blk = bt[wave / CPB], sub = (wave % CPB) * CHUNK;
-        const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(0 * H + h) * KV_BLOCK + sub) * HD);
-        const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(1 * H + h) * KV_BLOCK + sub) * HD);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) kk[i] = NT ? ld_nt(Kp + i * 64 + lane) : Kp[i * 64 + lane];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) vv[i] = NT ? ld_nt(Vp + i * 64 + lane) : Vp[i * 64 + lane];
-    }
-    float kn[8], vn[8];                 // FUSE: the row's own (newest) key / value, dims 8*e8..8*e8+7
+    if (wave < nc) load_tiles(wave);
+
+    uint4 qfrag[2];                                 // B operand: q[32 ds + 8 kg .. +7], the same in all 16 columns
+    uint4 knf[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};      // FUSE: the newest key in A-fragment form
+    uint32_t vnew[4] = {0, 0, 0, 0};                // FUSE: the newest value, dims 16 dt + col
     if constexpr (FUSE) {
-        // RoPE of this head's q and k exactly as rope_kv_kernel does it (same products, same roundings), then the
-        // paged K/V write; the newest token is taken from registers below instead of being re-read from HBM.
+        // RoPE of this head's q and k exactly as rope_kv_kernel does it (same products, same roundings): a lane holds
+        // both halves of its rotation pairs (dims 8 kg + j and 32 + 8 kg + j), i.e. exactly its two operand fragments.
         const int pos = L - 1;
-        const uint16_t* src = a.qkv + (size_t)row * QKV + h * HD + e8 * 8;
-        float xq[8], xk[8], c[8], s[8];
-        unpack8(*reinterpret_cast<const uint4*>(src), xq);
-        unpack8(*reinterpret_cast<const uint4*>(src + D), xk);
-        unpack8(*reinterpret_cast<const uint4*>(src + 2 * D), vn);
-        const float4* cp = reinterpret_cast<const float4*>(a.cos_t + (size_t)pos * 32 + (e8 & 3) * 8);
-        const float4* sp = reinterpret_cast<const float4*>(a.sin_t + (size_t)pos * 32 + (e8 & 3) * 8);
-        const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
-        c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
-        s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
-        const bool upper = e8 >= 4;     // dims 32..63 pair with dims 0..31 held by lane ^ 4
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float pq = __shfl_xor(xq[e], 4), pk = __shfl_xor(xk[e], 4);
-            // lower: x1*c - x2*s ; upper: x2*c + x1*s   (x1 = lower half, x2 = upper half)
-            const float rq = upper ? (xq[e] * c[e] + pq * s[e]) : (xq[e] * c[e] - pq * s[e]);
-            const float rk = upper ? (xk[e] * c[e] + pk * s[e]) : (xk[e] * c[e] - pk * s[e]);
-            qf[e] = rbf(rq); kn[e] = rbf(rk);
+        const uint16_t* src = a.qkv + (size_t)row * QKV + h * HD;
+        float c[8], s[8];
+        {
+            const float4* cp = reinterpret_cast<const float4*>(a.cos_t + (size_t)pos * 32 + kg * 8);
+            const float4* sp = reinterpret_cast<const float4*>(a.sin_t + (size_t)pos * 32 + kg * 8);
+            const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+            c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+            s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
         }
-        if (wave == 0 && g == 0) {
+        rope8(*reinterpret_cast<const uint4*>(src + kg * 8), *reinterpret_cast<const uint4*>(src + 32 + kg * 8), c, s, qfrag[0], qfrag[1]);
+        rope8(*reinterpret_cast<const uint4*>(src + D + kg * 8), *reinterpret_cast<const uint4*>(src + D + 32 + kg * 8), c, s, knf[0], knf[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vnew[dt] = src[2 * D + 16 * dt + col];
+        if (wave == 0) {                            // paged write of the newest K / V (for the following steps)
             const int blk = bt[pos / KV_BLOCK], tok = pos % KV_BLOCK;
-            uint16_t* kb = a.kv_layer_w + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(0 * H + h) * KV_BLOCK + tok) * HD + e8 * 8;
-            uint16_t* vb = a.kv_layer_w + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(1 * H + h) * KV_BLOCK + tok) * HD + e8 * 8;
-            uint4 ko, vo;
-            ko.x = pack2(kn[0], kn[1]); ko.y = pack2(kn[2], kn[3]); ko.z = pack2(kn[4], kn[5]); ko.w = pack2(kn[6], kn[7]);
-            vo.x = pack2(vn[0], vn[1]); vo.y = pack2(vn[2], vn[3]); vo.z = pack2(vn[4], vn[5]); vo.w = pack2(vn[6], vn[7]);
-            *reinterpret_cast<uint4*>(kb) = ko; *reinterpret_cast<uint4*>(vb) = vo;
+            uint16_t* kb = a.kv_layer_w + kv_head_base(blk, 0, h);
+            uint16_t* vb = a.kv_layer_w + kv_head_base(blk, 1, h);
+            if (col == 0) {
+                *reinterpret_cast<uint4*>(kb + k_slot(tok, 0, kg)) = knf[0];
+                *reinterpret_cast<uint4*>(kb + k_slot(tok, 1, kg)) = knf[1];
+            }
+            if (kg == 0) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) vb[v_elem(tok, 16 * dt + col)] = (uint16_t)vnew[dt];
+            }
         }
     } else {
-        unpack8(*reinterpret_cast<const uint4*>(a.q + (size_t)row * D + h * HD + e8 * 8), qf);
+        const uint16_t* qsrc = a.q + (size_t)row * D + h * HD + kg * 8;
+        qfrag[0] = *reinterpret_cast<const uint4*>(qsrc); qfrag[1] = *reinterpret_cast<const uint4*>(qsrc + 32);
     }
 
     for (int c = wave; c < nc; c += NW) {
-        if (c != wave) {
-            const int blk = bt[c / CPB], sub = (c % CPB) * CHUNK;
-            const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(0 * H + h) * KV_BLOCK + sub) * HD);
-            const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(1 * H + h) * KV_BLOCK + sub) * HD);
+        if (c != wave) load_tiles(c);
+        if (FUSE && c == nc - 1) {                  // the newest token is patched into the last tile from registers
+            const int tc = L - 1 - c * CHUNK;
+            const int tts = tc >> 4, ts = tc & 15, tss = tc >> 5, kgs = (tc & 31) >> 3, js = tc & 7;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) kk[i] = NT ? ld_nt(Kp + i * 64 + lane) : Kp[i * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) vv[i] = NT ? ld_nt(Vp + i * 64 + lane) : Vp[i * 64 + lane];
-        }
-        float sc[8];
-        float m = -INFINITY;
-        const int tnew = FUSE ? (L - 1 - c * CHUNK) : -1;          // index of the newest token inside this chunk (last chunk only)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float kf[8]; unpack8(kk[i], kf);
-            if (FUSE && tnew == 8 * i + g) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) kf[e] = kn[e];
+            for (int tt = 0; tt < 4; ++tt) {
+                const bool hit = (tt == tts) && (col == ts);
+                kf[2 * tt].x = hit ? knf[0].x : kf[2 * tt].x; kf[2 * tt].y = hit ? knf[0].y : kf[2 * tt].y;
+                kf[2 * tt].z = hit ? knf[0].z : kf[2 * tt].z; kf[2 * tt].w = hit ? knf[0].w : kf[2 * tt].w;
+                kf[2 * tt + 1].x = hit ? knf[1].x : kf[2 * tt + 1].x; kf[2 * tt + 1].y = hit ? knf[1].y : kf[2 * tt + 1].y;
+                kf[2 * tt + 1].z = hit ? knf[1].z : kf[2 * tt + 1].z; kf[2 * tt + 1].w = hit ? knf[1].w : kf[2 * tt + 1].w;
             }
-            float s = 0.0f;
+            if (kg == kgs) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s = __builtin_fmaf(qf[e], kf[e], s);
-            s = s + __shfl_xor(s, 1); s = s + __shfl_xor(s, 2); s = s + __shfl_xor(s, 4);
-            const int t = c * CHUNK + 8 * i + g;
-            sc[i] = (t < L) ? s * 0.125f : -INFINITY;
-            m = fmaxf(m, sc[i]);
-        }
-        m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
-        float p[8], lsum = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { p[i] = (sc[i] == -INFINITY) ? 0.0f : t3_expf(sc[i] - m); lsum = lsum + p[i]; }
-        lsum = lsum + __shfl_xor(lsum, 8); lsum = lsum + __shfl_xor(lsum, 16); lsum = lsum + __shfl_xor(lsum, 32);
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float vf[8]; unpack8(vv[i], vf);
-            if (FUSE && tnew == 8 * i + g) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vf[e] = vn[e];
+                for (int dt = 0; dt < 4; ++dt) {
+                    if (tss == 0) patch16(vf[2 * dt], js, vnew[dt]); else patch16(vf[2 * dt + 1], js, vnew[dt]);
+                }
             }
-            const bool valid = (c * CHUNK + 8 * i + g) < L;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(p[i], valid ? vf[e] : 0.0f, o[e]);
         }
+        // ---- scores on the matrix cores: D[token][col] = K[token][:] . q
+        f32x4 sacc[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = o[e];
-            v = v + __shfl_xor(v, 8); v = v + __shfl_xor(v, 16); v = v + __shfl_xor(v, 32);
-            o[e] = v;
+        for (int tt = 0; tt < 4; ++tt) {
+            sacc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            sacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf[2 * tt]), as_frag(qfrag[0]), sacc[tt], 0, 0, 0);
+            sacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf[2 * tt + 1]), as_frag(qfrag[1]), sacc[tt], 0, 0, 0);
         }
-        if (g == 0) {
+        if (col == 0) {                             // lanes 0,16,32,48 hold every score once: rows 4 kg + r of each token tile
 #pragma unroll
-            for (int e = 0; e < 8; ++e) po[c * 64 + e8 * 8 + e] = o[e];
+            for (int tt = 0; tt < 4; ++tt)
+                *reinterpret_cast<float4*>(sbuf + 16 * tt + 4 * kg) = make_float4(sacc[tt][0], sacc[tt][1], sacc[tt][2], sacc[tt][3]);
+        }
+        asm volatile("" ::: "memory");              // wave-private LDS exchange: keep the reads below the writes (the hardware keeps a wave's DS ops in order)
+        // ---- softmax statistics, lane = token
+        const bool live = (c * CHUNK + lane) < L;
+        const float sc = live ? sbuf[lane] * 0.125f : -INFINITY;
+        float m = sc;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        const float p = live ? t3_expf(sc - m) : 0.0f;
+        float lsum = p;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) lsum = lsum + __shfl_xor(lsum, off);
+        pbuf[lane] = (p < 0x1p-100f) ? (uint16_t)0 : (uint16_t)f2bf(p);
+        asm volatile("" ::: "memory");
+        uint4 pfrag[2];                             // B operand: p[32 ts + 8 kg .. +7] as bf16, the same in all 16 columns
+        pfrag[0] = *reinterpret_cast<const uint4*>(pbuf + 8 * kg);
+        pfrag[1] = *reinterpret_cast<const uint4*>(pbuf + 32 + 8 * kg);
+        // ---- P.V on the matrix cores: D[dim][col] = sum_token V[token][dim] * p[token]
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf[2 * dt]), as_frag(pfrag[0]), oacc[dt], 0, 0, 0);
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf[2 * dt + 1]), as_frag(pfrag[1]), oacc[dt], 0, 0, 0);
+        }
+        if (col == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<float4*>(po + c * 64 + 16 * dt + 4 * kg) = make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
         }
         if (lane == 0) { pm[c] = m; pl[c] = lsum; }
+        asm volatile("" ::: "memory");              // the next chunk reuses sbuf / pbuf
     }
     __syncthreads();
     if (wave == 0) {
@@ -568,11 +604,11 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
 }
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
-    const size_t lds = (size_t)a.max_chunks * 66 * sizeof(float);
     static int nw = 0, nt = 0;
     if (!nw) { const char* e = getenv("T3_ATTN_WAVES"); nw = e ? atoi(e) : 4; const char* t = getenv("T3_ATTN_NT"); nt = t ? atoi(t) : 1; }
     const dim3 grid(H, a.rows);
     const bool fuse = a.qkv != nullptr;
+    const size_t lds = ((size_t)a.max_chunks * 66 + (size_t)(nw == 8 ? 8 : 4) * 96) * sizeof(float);
 #define T3_ATTN(NW, NTF, FU) hipLaunchKernelGGL((attention_kernel<NW, NTF, FU>), grid, dim3(NW * 64), lds, s, a)
     if (nw == 8) { if (fuse) { if (nt) T3_ATTN(8, true, true); else T3_ATTN(8, false, true); } else { if (nt) T3_ATTN(8, true, false); else T3_ATTN(8, false, false); } }
     else { if (fuse) { if (nt) T3_ATTN(4, true, true); else T3_ATTN(4, false, true); } else { if (nt) T3_ATTN(4, true, false); else T3_ATTN(4, false, false); } }

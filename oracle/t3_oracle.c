@@ -349,67 +349,40 @@ void orc_rope(uint16_t* qk /* [rows][1024] */, const int* pos, int rows, const f
 
 /* ------------------------------------------------------------------ attention (one query row, one head)
  * K,V: [L][stride] bf16 with this head's 64 values at kv[t*stride .. +64).
- * Context is cut into position-aligned chunks of 64 tokens.  Inside chunk c, "lane"
- * l = 8g + e8 handles tokens t = 64c + 8i + g (i = 0..7) and dims 8*e8 .. 8*e8+7:
- *   score partial = sequential q*k adds over the lane's 8 dims; butterfly add xor 1,2,4;
- *   s = partial * 0.125; masked (t >= L) -> -inf
- *   m_c = max over i, then over lanes (exact);  p = exp(s - m_c), masked -> 0
- *   l_c: per lane sequential add over i, butterfly add xor 8,16,32
- *   o_c[d]: per lane o = fma(p_i, v, o) over i, butterfly add xor 8,16,32
+ * Context is cut into position-aligned chunks of 64 tokens; inside chunk c "lane" t is token 64c + t:
+ *   score_t = MFMA chain over the 64 dims (8 blocks of 8 dims, ascending, from +0) of k_t . q;  s_t = score_t * 0.125,
+ *             masked (position >= L) -> -inf
+ *   m_c = max_t s_t (exact);  p_t = exp(s_t - m_c), masked -> 0
+ *   l_c = 64-lane butterfly add of p (xor 32,16,8,4,2,1), fp32, UNROUNDED p
+ *   pb_t = bf16(p_t), flushed to 0 below 2^-100 (the probabilities enter P.V in bf16, as in the bf16 HF / vLLM pipeline)
+ *   o_c[d] = MFMA chain over the 64 tokens (8 blocks of 8 tokens, ascending, from +0) of v_t[d] . pb_t
  * Across chunks: M = max m_c; ascending c: w = exp(m_c - M); l = fma(w, l_c, l);
- *   o[d] = fma(w, o_c[d], o[d]);  out[d] = bf16(o[d] / l).                               */
+ *   o[d] = fma(w, o_c[d], o[d]);  out[d] = bf16(o[d] / l).                                   */
 void orc_attn_row(const uint16_t* q, const uint16_t* K, const uint16_t* Vv, int L, int stride, uint16_t* out) {
-    static const int o124[3] = {1, 2, 4}, o8[3] = {8, 16, 32};
+    static const int offs[6] = {32, 16, 8, 4, 2, 1};
     const int nc = (L + T3_CHUNK - 1) / T3_CHUNK;
     float* mc = (float*)malloc(sizeof(float) * nc);
     float* lc = (float*)malloc(sizeof(float) * nc);
     float* oc = (float*)malloc(sizeof(float) * nc * 64);
-    float qf[64];
-    for (int d = 0; d < 64; ++d) qf[d] = bf2f(q[d]);
     for (int c = 0; c < nc; ++c) {
-        float s[8][64], p[8][64];
-        for (int i = 0; i < 8; ++i) {
-            float part[64];
-            for (int l = 0; l < 64; ++l) {
-                const int g = l >> 3, e0 = (l & 7) * 8, t = 64 * c + 8 * i + g;
-                float a = 0.0f;
-                if (t < L) for (int e = 0; e < 8; ++e) a = fmaf(qf[e0 + e], bf2f(K[(size_t)t * stride + e0 + e]), a);
-                part[l] = a;
-            }
-            bfly_add(part, o124, 3);
-            for (int l = 0; l < 64; ++l) {
-                const int t = 64 * c + 8 * i + (l >> 3);
-                s[i][l] = (t < L) ? part[l] * 0.125f : -INFINITY;
-            }
-        }
+        float s[64], p[64];
+        uint16_t pb[64], vcol[64];
         float m = -INFINITY;
-        for (int i = 0; i < 8; ++i) for (int l = 0; l < 64; ++l) m = fmaxf(m, s[i][l]);
-        float ls[64];
-        for (int l = 0; l < 64; ++l) {
-            float a = 0.0f;
-            for (int i = 0; i < 8; ++i) {
-                p[i][l] = (s[i][l] == -INFINITY) ? 0.0f : orc_expf(s[i][l] - m);
-                a = a + p[i][l];
-            }
-            ls[l] = a;
+        for (int t = 0; t < 64; ++t) {
+            const int pos = 64 * c + t;
+            s[t] = (pos < L) ? orc_mfma_bf16_dot(K + (size_t)pos * stride, q, 64, 0.0f) * 0.125f : -INFINITY;
+            m = fmaxf(m, s[t]);
         }
-        bfly_add(ls, o8, 3);
-        float o[8][64];   /* o[e][lane] */
-        for (int l = 0; l < 64; ++l) {
-            const int g = l >> 3, e0 = (l & 7) * 8;
-            for (int e = 0; e < 8; ++e) {
-                float a = 0.0f;
-                for (int i = 0; i < 8; ++i) {
-                    const int t = 64 * c + 8 * i + g;
-                    const float v = (t < L) ? bf2f(Vv[(size_t)t * stride + e0 + e]) : 0.0f;
-                    a = fmaf(p[i][l], v, a);
-                }
-                o[e][l] = a;
-            }
+        for (int t = 0; t < 64; ++t) {
+            p[t] = (s[t] == -INFINITY) ? 0.0f : orc_expf(s[t] - m);
+            pb[t] = (p[t] < 0x1p-100f) ? 0 : f2bf(p[t]);
         }
-        for (int e = 0; e < 8; ++e) bfly_add(o[e], o8, 3);
-        mc[c] = m; lc[c] = ls[0];
-        for (int e8 = 0; e8 < 8; ++e8) for (int e = 0; e < 8; ++e) oc[c * 64 + e8 * 8 + e] = o[e][e8];
+        bfly_add(p, offs, 6);
+        for (int d = 0; d < 64; ++d) {
+            for (int t = 0; t < 64; ++t) { const int pos = 64 * c + t; vcol[t] = (pos < L) ? Vv[(size_t)pos * stride + d] : 0; }
+            oc[c * 64 + d] = orc_mfma_bf16_dot(vcol, pb, 64, 0.0f);
+        }
+        mc[c] = m; lc[c] = p[0];
     }
     float M = -INFINITY;
     for (int c = 0; c < nc; ++c) M = fmaxf(M, mc[c]);
