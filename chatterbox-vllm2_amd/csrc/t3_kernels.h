@@ -13,7 +13,13 @@ constexpr int CHUNK = 64;                          // attention chunk in tokens 
 #define T3_KV_BLOCK 256
 #endif
 constexpr int KV_BLOCK = T3_KV_BLOCK;              // tokens per physical KV block (a multiple of CHUNK): per head 32 KiB K + 32 KiB V contiguous
-constexpr int KV_BLOCK_ELEMS = 2 * H * KV_BLOCK * HD;  // per layer per block: K then V, [kv][head][tok][64]
+#ifndef T3_KV_PAD
+#define T3_KV_PAD 512
+#endif
+constexpr int KV_HEAD_PAD = T3_KV_PAD;               // elements of padding after every (kv, head) region: breaks the power-of-two
+                                                   // strides (32 KiB per head, 512 KiB K->V) that make concurrent workgroups hit the same HBM channels
+constexpr int KV_HEAD_ELEMS = KV_BLOCK * HD + KV_HEAD_PAD;
+constexpr int KV_BLOCK_ELEMS = 2 * H * KV_HEAD_ELEMS;  // per layer per block: [kv][head][chunk][8 fragments][64 lanes][8]
 
 enum GemmEpi { EPI_F32 = 0, EPI_BF16 = 1, EPI_RESID = 2, EPI_SILU = 3 };
 

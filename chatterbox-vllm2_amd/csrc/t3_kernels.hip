@@ -398,7 +398,7 @@ __device__ __forceinline__ void rope8(const uint4& x1, const uint4& x2, const fl
 //   V fragment (dt, ts), lane d + 16 kg, element j  =  V[token 32 ts + 8 kg + j of the chunk][dim 16 dt + d]    (MFMA A operand: rows = dims)
 // so the attention kernel feeds v_mfma_f32_16x16x32_bf16 straight from fully coalesced 1 KiB wave loads.
 __device__ __forceinline__ size_t kv_head_base(int blk, int kv, int h) {
-    return (size_t)blk * KV_BLOCK_ELEMS + ((size_t)(kv * H + h) * KV_BLOCK) * HD;
+    return (size_t)blk * KV_BLOCK_ELEMS + (size_t)(kv * H + h) * KV_HEAD_ELEMS;
 }
 __device__ __forceinline__ size_t k_slot(int tok_in_block, int ds, int kg) {      // start of the 8-element (16 B) piece
     const int ci = tok_in_block / CHUNK, tc = tok_in_block % CHUNK;
