@@ -66,6 +66,7 @@ struct T3Engine {
     int64_t n_blocks = 0;      // pool
     int rmax = 0;              // row budget per step (all groups)
     int n_groups = 1;
+    int row_stride = 0;        // int32 words per row record
     bool fuse_rope = true;
 
     // weights (device)
@@ -83,12 +84,12 @@ struct T3Engine {
 
     // utterance groups: each group owns a stream, activation buffers, step metadata and captured graphs, so that
     // one group's HBM-bound attention overlaps another group's latency-bound GEMM chain on the same GPU
-    struct Meta { int* row_stream; int* row_pos; int4* desc; int* sel_rows; int4* sel; int* out_tok; };
+    struct Meta { int* sel_rows; int4* sel; int* rows; int* out_tok; };   // sel arrays first, then the row records (one contiguous upload)
     struct Group {
         hipStream_t stream = nullptr;
         uint16_t *h = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *act = nullptr, *logits = nullptr;
         char *h_meta = nullptr, *d_meta = nullptr;
-        size_t meta_bytes = 0;
+        size_t meta_bytes = 0, meta_rows_off = 0;
         Meta hm{}, dm{};
         int* h_out_tok = nullptr;
         int rcap = 0;              // row budget per step
@@ -148,6 +149,7 @@ extern "C" int t3_create(const T3EngineConfig* cfg, T3Handle* out) {
     if (e->cfg.cfg_scale != e->cfg.cfg_scale) e->cfg.cfg_scale = 0.5f;
     e->layers.resize(cfg->n_layers);
     e->max_blocks = (cfg->max_model_len + KV_BLOCK - 1) / KV_BLOCK;
+    e->row_stride = row_stride_words(e->max_blocks);
     e->rmax = cfg->max_batched_rows > 0 ? cfg->max_batched_rows : std::max(2048, 2 * cfg->max_seqs);
     e->rmax = std::max(e->rmax, 2 * cfg->max_seqs);
     e->slot_req.assign(cfg->max_seqs, -1);
@@ -335,13 +337,14 @@ extern "C" int t3_finalize_weights(T3Handle e) {
         if ((rc = dalloc(e, &g.logits, 2 * Sg * VPAD, true))) return rc;
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-        const size_t o_rs = carve(R * 4), o_rp = carve(R * 4), o_desc = carve(R * 16), o_selr = carve(2 * Sg * 4), o_sel = carve(Sg * 16);
+        const size_t o_selr = carve(2 * Sg * 4), o_sel = carve(Sg * 16), o_rows = carve(R * (size_t)e->row_stride * 4);
+        g.meta_rows_off = o_rows;
         g.meta_bytes = off;
         HIP_TRY(hipHostMalloc((void**)&g.h_meta, g.meta_bytes, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void**)&g.d_meta, g.meta_bytes));
+        memset(g.h_meta, 0, g.meta_bytes);
         auto fill = [&](T3Engine::Meta& m, char* base) {
-            m.row_stream = (int*)(base + o_rs); m.row_pos = (int*)(base + o_rp); m.desc = (int4*)(base + o_desc);
-            m.sel_rows = (int*)(base + o_selr); m.sel = (int4*)(base + o_sel); m.out_tok = nullptr;
+            m.sel_rows = (int*)(base + o_selr); m.sel = (int4*)(base + o_sel); m.rows = (int*)(base + o_rows); m.out_tok = nullptr;
         };
         fill(g.hm, g.h_meta); fill(g.dm, g.d_meta);
         int* dtok = nullptr;
@@ -353,7 +356,6 @@ extern "C" int t3_finalize_weights(T3Handle e) {
     if ((rc = dalloc(e, &e->d_counts, S * VPAD, true))) return rc;
     if ((rc = dalloc(e, &e->d_sp, S, true))) return rc;
     if (e->cfg.debug_logits && (rc = dalloc(e, &e->d_dbg, S * V, true))) return rc;
-    if ((rc = dalloc(e, &e->d_block_table, 2 * S * e->max_blocks, true))) return rc;
     e->h_block_table.assign(2 * S * e->max_blocks, 0);
     HIP_TRY(t3::prepare_kernels());
     // KV pool
@@ -439,8 +441,7 @@ static int admit(T3Engine* e) {
         // r.cond / r.sp are kept alive in the request map until the copy is consumed (stream-ordered, pageable -> staged synchronously)
         e->running.push_back(r.id);
     }
-    if (table_dirty)
-        HIP_TRY(hipMemcpyAsync(e->d_block_table, e->h_block_table.data(), e->h_block_table.size() * 4, hipMemcpyHostToDevice, e->stream));
+    (void)table_dirty;   // block ids reach the device inside the per-step row records
     HIP_TRY(hipEventRecord(e->ev_admit, e->stream));
     e->st.kv_blocks_free = (int64_t)e->free_blocks.size();
     return T3_OK;
@@ -465,7 +466,7 @@ static int launch_step(T3Engine* e, T3Engine::Group& g) {
     const int M = g.M, n_sel = g.n_sel;
     {
         Prof p(e, K_EMBED, s);
-        EmbedArgs ea{g.dm.desc, e->d_cond, e->text_emb, e->text_pos, e->speech_emb, e->speech_pos, g.h, M};
+        EmbedArgs ea{g.dm.rows, e->row_stride, e->d_cond, e->text_emb, e->text_pos, e->speech_emb, e->speech_pos, g.h, M};
         HIP_TRY(launch_embed(ea, s));
     }
     const size_t layer_elems = (size_t)e->n_blocks * KV_BLOCK_ELEMS;
@@ -478,11 +479,11 @@ static int launch_step(T3Engine* e, T3Engine::Group& g) {
         if (g.n_prefill_rows == 0 && e->fuse_rope) {
             // decode-only step: every row is the newest position of its stream -> RoPE + KV write inside the attention kernel
             Prof p(e, K_ATTN, s);
-            AttnArgs aa{nullptr, kvL, g.dm.row_stream, g.dm.row_pos, e->d_block_table, e->max_blocks, g.att, M, max_chunks, g.qkv, kvL, e->cos_t, e->sin_t};
+            AttnArgs aa{nullptr, kvL, g.dm.rows, e->row_stride, g.att, M, max_chunks, g.qkv, kvL, e->cos_t, e->sin_t};
             HIP_TRY(launch_attention(aa, s));
         } else {
-            { Prof p(e, K_ROPE, s); RopeArgs ra{g.qkv, g.qrot, kvL, g.dm.row_stream, g.dm.row_pos, e->d_block_table, e->max_blocks, e->cos_t, e->sin_t, M}; HIP_TRY(launch_rope_kv(ra, s)); }
-            { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot, kvL, g.dm.row_stream, g.dm.row_pos, e->d_block_table, e->max_blocks, g.att, M, max_chunks, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(launch_attention(aa, s)); }
+            { Prof p(e, K_ROPE, s); RopeArgs ra{g.qkv, g.qrot, kvL, g.dm.rows, e->row_stride, e->cos_t, e->sin_t, M}; HIP_TRY(launch_rope_kv(ra, s)); }
+            { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot, kvL, g.dm.rows, e->row_stride, g.att, M, max_chunks, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(launch_attention(aa, s)); }
         }
         { Prof p(e, K_O, s); GemmArgs a{g.att, (const uint4*)y.o, M, D, D, g.h, D, 16, nullptr, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
         { Prof p(e, K_GU, s); GemmArgs a{g.h, (const uint4*)y.gu, M, D, F, g.act, F, 4, y.ln2, nullptr}; HIP_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s)); }
@@ -508,7 +509,10 @@ extern "C" int t3_step(T3Handle e, T3StepResult* res) {
     // ---- build rows per group: decode rows of every running utterance, then prefill rows within the group's budget
     for (auto& g : e->groups) { g.M = g.n_sel = g.n_prefill_rows = g.decode_rows = 0; g.sum_ctx = 0; g.sampled.clear(); }
     auto add_row = [&](T3Engine::Group& g, int stream, int pos, int kind, int a, int b) {
-        g.hm.row_stream[g.M] = stream; g.hm.row_pos[g.M] = pos; g.hm.desc[g.M] = make_int4(kind, a, b, 0); ++g.M;
+        int* rec = g.hm.rows + (size_t)g.M * e->row_stride;
+        rec[0] = stream; rec[1] = pos; rec[2] = kind; rec[3] = a; rec[4] = b;
+        memcpy(rec + ROW_HDR, &e->h_block_table[(size_t)stream * e->max_blocks], (size_t)e->max_blocks * 4);
+        ++g.M;
     };
     for (int64_t id : e->running) {
         Request& r = e->reqs[id];
@@ -550,7 +554,7 @@ extern "C" int t3_step(T3Handle e, T3StepResult* res) {
     for (auto& g : e->groups) {
         if (g.M == 0) continue;
         HIP_TRY(hipStreamWaitEvent(g.stream, e->ev_admit, 0));
-        HIP_TRY(hipMemcpyAsync(g.d_meta, g.h_meta, g.meta_bytes, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(g.d_meta, g.h_meta, g.meta_rows_off + (size_t)g.M * e->row_stride * 4, hipMemcpyHostToDevice, g.stream));   // sel arrays + the used row records
         const bool use_graph = !e->cfg.enforce_eager && !e->profile && g.n_prefill_rows == 0;
         if (use_graph) {
             const auto key = std::make_pair(g.M, g.n_sel);

@@ -114,13 +114,20 @@ extern "C" int t3k_rope_attention(const void* qkv, const int32_t* row_stream, co
     }
     std::vector<float> c((size_t)max_pos * 32), s((size_t)max_pos * 32);
     rope_tables(max_pos, c.data(), s.data());
-    DevBuf dqkv, drs, drp, dbt, dc, ds, dq, dkv, dout;
-    K_TRY(dqkv.from(qkv, (size_t)rows * QKV * 2)); K_TRY(drs.from(row_stream, rows * 4)); K_TRY(drp.from(row_pos, rows * 4));
-    K_TRY(dbt.from(table.data(), table.size() * 4)); K_TRY(dc.from(c.data(), c.size() * 4)); K_TRY(ds.from(s.data(), s.size() * 4));
+    const int stride = row_stride_words(max_blocks);
+    std::vector<int> recs((size_t)rows * stride, 0);
+    for (int r = 0; r < rows; ++r) {
+        int* rec = recs.data() + (size_t)r * stride;
+        rec[0] = row_stream[r]; rec[1] = row_pos[r];
+        for (int b = 0; b < max_blocks; ++b) rec[ROW_HDR + b] = table[(size_t)row_stream[r] * max_blocks + b];
+    }
+    DevBuf dqkv, drec, dc, ds, dq, dkv, dout;
+    K_TRY(dqkv.from(qkv, (size_t)rows * QKV * 2)); K_TRY(drec.from(recs.data(), recs.size() * 4));
+    K_TRY(dc.from(c.data(), c.size() * 4)); K_TRY(ds.from(s.data(), s.size() * 4));
     K_TRY(dq.alloc((size_t)rows * D * 2)); K_TRY(dkv.alloc((size_t)nb * KV_BLOCK_ELEMS * 2, true)); K_TRY(dout.alloc((size_t)rows * D * 2, true));
-    RopeArgs ra{dqkv.as<uint16_t>(), dq.as<uint16_t>(), dkv.as<uint16_t>(), drs.as<int>(), drp.as<int>(), dbt.as<int>(), max_blocks, dc.as<float>(), ds.as<float>(), rows};
+    RopeArgs ra{dqkv.as<uint16_t>(), dq.as<uint16_t>(), dkv.as<uint16_t>(), drec.as<int>(), stride, dc.as<float>(), ds.as<float>(), rows};
     K_TRY(launch_rope_kv(ra, nullptr));
-    AttnArgs aa{dq.as<uint16_t>(), dkv.as<uint16_t>(), drs.as<int>(), drp.as<int>(), dbt.as<int>(), max_blocks, dout.as<uint16_t>(), rows, (max_pos + CHUNK - 1) / CHUNK, nullptr, nullptr, nullptr, nullptr};
+    AttnArgs aa{dq.as<uint16_t>(), dkv.as<uint16_t>(), drec.as<int>(), stride, dout.as<uint16_t>(), rows, (max_pos + CHUNK - 1) / CHUNK, nullptr, nullptr, nullptr, nullptr};
     K_TRY(launch_attention(aa, nullptr));
     K_TRY(hipDeviceSynchronize());
     K_TRY(hipMemcpy(out, dout.p, (size_t)rows * D * 2, hipMemcpyDeviceToHost));

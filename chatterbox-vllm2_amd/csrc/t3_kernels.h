@@ -43,8 +43,14 @@ void pack_gate_up(const uint16_t* Wg, const uint16_t* Wu, int Fdim, int K, uint1
 int choose_mt(int M, int ntiles_x, int nw = 4, bool norm = false);
 hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s);
 
+// Per-row record of a step (int32 words), built by the scheduler and uploaded once per step:
+//   [0] stream  [1] position  [2] embed kind  [3] embed a  [4] embed b  [5..7] unused  [8 ..] KV block ids of the row's stream
+// One lookup gives a kernel everything it needs to address the row's paged KV (no stream -> block-table hop).
+constexpr int ROW_HDR = 8;
+inline int row_stride_words(int max_blocks) { return ROW_HDR + ((max_blocks + 3) & ~3); }
+
 struct EmbedArgs {
-    const int4* desc;          // per row {kind, a, b, c}
+    const int* rowrec; int row_stride;   // row records
     const float* cond;         // [max_seqs][34][1024] fp32
     const uint16_t *text_emb, *text_pos, *speech_emb, *speech_pos;
     uint16_t* h;               // [rows][1024]
@@ -57,8 +63,7 @@ struct RopeArgs {
     const uint16_t* qkv;       // [rows][3072]
     uint16_t* q_out;           // [rows][1024]
     uint16_t* kv_layer;        // pool + layer*n_blocks*KV_BLOCK_ELEMS
-    const int *row_stream, *row_pos, *block_table;
-    int max_blocks;            // block_table row stride
+    const int* rowrec; int row_stride;   // row records
     const float *cos_t, *sin_t;  // [max_pos][32]
     int rows;
 };
@@ -67,8 +72,7 @@ hipError_t launch_rope_kv(const RopeArgs& a, hipStream_t s);
 struct AttnArgs {
     const uint16_t* q;         // [rows][1024] rotated (unfused form)
     const uint16_t* kv_layer;
-    const int *row_stream, *row_pos, *block_table;
-    int max_blocks;
+    const int* rowrec; int row_stride;   // row records
     uint16_t* out;             // [rows][1024]
     int rows;
     int max_chunks;            // LDS sizing: ceil(max_model_len/64)

@@ -353,7 +353,8 @@ __device__ __forceinline__ uint4 add_bf8(const uint4& a, const uint4& b) {
 __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
-    const int4 d = a.desc[row];
+    const int* rec = a.rowrec + (size_t)row * a.row_stride;
+    const int4 d = make_int4(rec[2], rec[3], rec[4], 0);
     uint4* out = reinterpret_cast<uint4*>(a.h + (size_t)row * D);
     if (d.x == EMB_ZERO) {
         out[lane] = make_uint4(0, 0, 0, 0); out[64 + lane] = make_uint4(0, 0, 0, 0);
@@ -412,8 +413,9 @@ __device__ __forceinline__ size_t v_elem(int tok_in_block, int dim) {           
 __global__ __launch_bounds__(256) void rope_kv_kernel(RopeArgs a) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
-    const int pos = a.row_pos[row], stream = a.row_stream[row];
-    const int blk = a.block_table[(size_t)stream * a.max_blocks + pos / KV_BLOCK], tok = pos % KV_BLOCK;
+    const int* rec = a.rowrec + (size_t)row * a.row_stride;
+    const int pos = rec[1];
+    const int blk = rec[ROW_HDR + pos / KV_BLOCK], tok = pos % KV_BLOCK;
     const int h = lane >> 2, part = lane & 3, i0 = part * 8;
     float c[8], s[8];
     {
@@ -467,10 +469,11 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
     float* sbuf = part + 66 * a.max_chunks + wave * 96;            // 64 floats of scores, then 64 bf16 (32 floats) of probabilities
     uint16_t* pbuf = reinterpret_cast<uint16_t*>(sbuf + 64);
     const int h = blockIdx.x, row = blockIdx.y;
-    const int stream = a.row_stream[row], L = a.row_pos[row] + 1;
+    const int* rec = a.rowrec + (size_t)row * a.row_stride;
+    const int L = rec[1] + 1;
     const int nc = (L + CHUNK - 1) / CHUNK;
     const int col = lane & 15, kg = lane >> 4;
-    const int* bt = a.block_table + (size_t)stream * a.max_blocks;
+    const int* bt = rec + ROW_HDR;                 // the row's KV block ids travel with the row record
     constexpr int CPB = KV_BLOCK / CHUNK;          // chunks per physical block
 
     uint4 kf[8], vf[8];                            // K fragments (tt, ds) at 2 tt + ds; V fragments (dt, ts) at 2 dt + ts
