@@ -252,14 +252,17 @@ int choose_mt(int M, int ntiles_x, int nw, bool norm) {
     const int mtiles = (M + 15) / 16;
     if (const char* e = getenv("T3_GEMM_MT")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) return v; }
     // Largest row tile that (a) fits the register file (NORM form: 2 m-tiles; 16-wave form: 4) and (b) still launches
-    // >= 256 workgroups, one per CU.  Workgroups with the same blockIdx.x differ by a multiple of gridDim.x in linear
-    // id, and every gridDim.x used here is a multiple of 8, so they land on the same XCD and share the weight tile in L2.
-    const int cap = norm ? 2 : (nw == 16 ? 4 : 8);
+    // enough workgroups: >= 512 for the 4-wave forms (measured: qkv is fastest at 768 workgroups, gate/up at 512),
+    // >= 256 for the 16-wave form.  Workgroups with the same blockIdx.x differ by a multiple of gridDim.x in linear id,
+    // and gridDim.x is a multiple of 8 for the layer GEMMs, so they land on the same XCD and share the weight tile in L2.
+    int cap = norm ? 2 : (nw == 16 ? 4 : 8);
+    if (norm) { if (const char* e = getenv("T3_GEMM_MT_NORM")) cap = atoi(e); }
+    const long want = nw == 16 ? 256 : 512;
     int best = 1;
     for (int mt = 1; mt <= cap; mt <<= 1) {
         if (mt > 1 && mt / 2 >= mtiles) break;
         const long wgs = (long)ntiles_x * ((mtiles + mt - 1) / mt);
-        if (mt == 1 || wgs >= 256) best = mt;
+        if (mt == 1 || wgs >= want) best = mt;
     }
     return best;
 }
@@ -267,7 +270,7 @@ int choose_mt(int M, int ntiles_x, int nw, bool norm) {
 template <int MT, int NT, int EPI, int NW, bool NORM>
 static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     // ring depth, bounded by the register file: 4-wave workgroups may use ~200 VGPRs, 16-wave ones 128
-    constexpr int PD = NW == 16 ? (MT <= 2 ? 4 : 2) : ((MT + NT) <= 6 ? 8 : 4);
+    constexpr int PD = NW == 16 ? (MT <= 2 ? 4 : 2) : (NORM ? (MT * NT <= 2 ? 8 : 4) : ((MT + NT) <= 6 ? 8 : 4));
     const int ntiles = (a.N + 15) / 16;           // EPI_SILU: N = F -> one workgroup per output tile (2 packed tiles)
     const int gx = (EPI == EPI_SILU) ? ntiles : (ntiles + NT - 1) / NT;
     const int gy = ((a.M + 15) / 16 + MT - 1) / MT;
@@ -547,6 +550,16 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
                 }
             }
         }
+#ifdef T3_ATTN_DRY
+        {   // diagnostic build only: same loads, no arithmetic (measures the memory structure of this kernel)
+            uint32_t x = 0;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) x ^= kf[f].x ^ kf[f].y ^ kf[f].z ^ kf[f].w ^ vf[f].x ^ vf[f].y ^ vf[f].z ^ vf[f].w;
+            if (lane == 0) { pm[c] = 0.0f; pl[c] = 1.0f; }
+            po[c * 64 + lane] = __uint_as_float(x & 0x3fffffffu);
+            continue;
+        }
+#endif
         // ---- scores on the matrix cores: D[token][col] = K[token][:] . q
         f32x4 sacc[4];
 #pragma unroll
