@@ -690,3 +690,29 @@ extern "C" int t3_kernel_ms(T3Handle e, const char* name, double* avg_ms, int64_
         }
     return e->fail(T3_E_NOTFOUND, "unknown kernel class");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Token post-filter: restatement of tts.py:300-365 + alignment_stream_analyzer.py:111-201 (token-heuristic version).
+// ------------------------------------------------------------------------------------------------
+extern "C" int t3_clean_tokens(const int32_t* ids, int32_t n, int32_t text_token_count, int32_t flags, int32_t* out, int32_t* reason) {
+    if ((!ids && n > 0) || !out || n < 0) return T3_E_INVALID;
+    int kept = 0, why = 0;
+    bool complete = false;
+    int completed_at = 0;
+    for (int i = 0; i < n; ++i) {
+        const int frame = i + 1;                                             // curr_frame_pos after the increment (:140)
+        int est = frame / 2; if (est > text_token_count - 1) est = text_token_count - 1;      // :144
+        if (!complete && est >= text_token_count - 3) { complete = true; completed_at = frame; }   // :148-151
+        const bool repetition = i >= 2 && ids[i] == ids[i - 1] && ids[i] == ids[i - 2];     // :203-213 (window of 8 >= 3)
+        const bool long_tail = complete && (frame - completed_at) >= 10;                    // :157-160
+        if (long_tail || repetition) { why = repetition ? 1 : 2; break; }                   // forced EOS logit 2^15 > 2^14 (tts.py:341-345)
+        out[kept++] = ids[i];
+    }
+    if (flags & 1) {                                                          // tts.py:514
+        int w = 0;
+        for (int i = 0; i < kept; ++i) if (out[i] >= 0 && out[i] < 6561) out[w++] = out[i];
+        kept = w;
+    }
+    if (reason) *reason = why;
+    return kept;
+}

@@ -61,7 +61,7 @@ class T3Stats(ct.Structure):
 ABI_SYMBOLS = [
     "t3_create", "t3_destroy", "t3_last_error", "t3_load_tensor", "t3_finalize_weights", "t3_add_request",
     "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_release_request",
-    "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_kernel_ms",
+    "t3_clean_tokens", "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_kernel_ms",
     "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_sample", "t3k_expf",
 ]
 
@@ -101,6 +101,7 @@ def load_library():
     L.t3_num_unfinished.argtypes = [vp]
     L.t3_get_output.argtypes = [vp, i64, vp, ct.POINTER(i32), ct.POINTER(i32)]
     L.t3_release_request.argtypes = [vp, i64]
+    L.t3_clean_tokens.argtypes = [vp, i32, i32, i32, vp, ct.POINTER(i32)]
     L.t3_debug_logits.argtypes = [vp, i64, vp]
     L.t3_stats.argtypes = [vp, ct.POINTER(T3Stats)]
     L.t3_reset_stats.argtypes = [vp]

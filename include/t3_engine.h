@@ -127,6 +127,17 @@ int t3_num_unfinished(T3Handle h);
 int t3_get_output(T3Handle h, int64_t req_id, int32_t* ids, int32_t* n, int32_t* finish_reason);
 int t3_release_request(T3Handle h, int64_t req_id);   /* forget a finished request */
 
+/* ---- token post-filter: ChatterboxTTS.analyze_and_clean_tokens (tts.py:300-365) driving the fork's
+ * token-heuristic AlignmentStreamAnalyzer.step (models/t3/inference/alignment_stream_analyzer.py:111-201), plus the
+ * range filter of tts.py:514.  Pure integer logic on the host (the reference does it with one CUDA tensor + .item()
+ * sync per token).  speech_ids: speech-space ids (already un-offset, tts.py:492); text_token_count as tts.py:496.
+ * The output is the prefix before the first token at which the analyzer forces EOS -- three identical tokens in a
+ * row, or >= 10 frames after the estimated end of the text (frame/2 >= text_token_count - 3).
+ * flags bit 0: also drop ids outside [0, 6561) (tts.py:514).  reason (nullable): 0 none, 1 repetition, 2 long tail.
+ * Returns the number of tokens written to out (capacity n), or a negative T3_E_* code.                        */
+int t3_clean_tokens(const int32_t* speech_ids, int32_t n, int32_t text_token_count, int32_t flags,
+                    int32_t* out, int32_t* reason);
+
 /* ---- parity / measurement hooks --------------------------------------------------------- */
 /* post-CFG logits [8194] (speech-space, before the 2500-wide -inf pad of t3.py:669-672) of the
  * most recent sampled step of req_id; needs cfg.debug_logits = 1. */

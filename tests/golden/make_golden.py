@@ -12,6 +12,7 @@ What comes from where:
   G5/G6 streams.npz    -- oracle token streams + post-CFG logits on seeded synthetic weights
                           (2-layer English, 2-layer multilingual batch, 30-layer short) -- regression
                           pins for both the oracle and the GPU engine.
+  G8  postfilter.json  -- decisions of the reference's AlignmentStreamAnalyzer (imported, CPU) over random / planted token lists
   G7  tokenizer.json   -- token ids of the fixed en/es utterances from the reference's
                           tokenizer JSON files via the `tokenizers` library.
 No reference source text is stored: only inputs and numeric outputs.
@@ -137,9 +138,46 @@ def g6_streams():
     print("G6 streams:", {k: v.shape for k, v in out.items()})
 
 
+def g8_postfilter():
+    """Decisions of the reference's AlignmentStreamAnalyzer (imported; run on CPU) driven by the loop of tts.py:329-350."""
+    import importlib
+    import_reference_leaf_modules()
+    m = types.ModuleType("chatterbox_vllm.models.t3.inference"); m.__path__ = [REF_PKG + "/models/t3/inference"]
+    sys.modules["chatterbox_vllm.models.t3.inference"] = m
+    asa = importlib.import_module("chatterbox_vllm.models.t3.inference.alignment_stream_analyzer")
+    rs = np.random.RandomState(3)
+    cases = []
+    def run(tokens, n_text):
+        an = asa.AlignmentStreamAnalyzer(text_tokens_count=n_text, eos_token_id=6562, device="cpu")
+        cleaned = []
+        for tok in tokens:
+            lg = an.step(torch.zeros(1, 8194), next_token=torch.tensor(tok))
+            if lg[0, 6562].item() > 2 ** 14:
+                break
+            cleaned.append(int(tok))
+        r = an.get_analysis_result()
+        return cleaned, bool(r.repetition), bool(r.long_tail)
+    specs = []
+    for n_text in (1, 2, 4, 6, 10, 42, 60, 200):
+        for length in (0, 1, 2, 3, 5, 30, 150, 400):
+            toks = rs.randint(0, 6561, size=length).tolist()
+            specs.append((toks, n_text))
+            if length >= 5:
+                t2 = list(toks); k = int(rs.randint(2, length)); t2[k] = t2[k - 1] = t2[k - 2]      # plant a triple
+                specs.append((t2, n_text))
+                t3 = list(toks); t3[-1] = 6562; t3[0] = 7000                                         # specials (range filter input)
+                specs.append((t3, n_text))
+    for toks, n_text in specs:
+        cleaned, rep, tail = run(toks, n_text)
+        cases.append({"tokens": toks, "text_token_count": n_text, "cleaned": cleaned, "repetition": rep, "long_tail": tail})
+    json.dump(cases, open(os.path.join(HERE, "postfilter.json"), "w"))
+    print("G8 postfilter:", len(cases), "cases,", sum(len(c["cleaned"]) < len(c["tokens"]) for c in cases), "truncated")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g7", "g6"]
+    which = sys.argv[1:] or ["g1", "g3", "g7", "g6", "g8"]
     if "g1" in which: g1_cond_enc()
     if "g3" in which: g3_rope()
     if "g7" in which: g7_tokenizer()
     if "g6" in which: g6_streams()
+    if "g8" in which: g8_postfilter()
