@@ -9,6 +9,7 @@
 // prefill and which are decode.
 #include <algorithm>
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -48,6 +49,11 @@ struct Request {
     int state = WAITING, slot = -1, n_prefilled = 0, finish_reason = 0, limit = 0;
     std::vector<int32_t> out;         // speech-space ids
     std::vector<int> blocks[2];
+    // run-ahead scheduling: tokens whose sampling has been enqueued (>= out.size(); the difference is in flight),
+    // index of the newest one in its group's sampler output array, and whether a row of an already finished
+    // request is still in flight (its slot is released when that step completes)
+    int n_sched = 0, last_idx = -1;
+    bool zombie = false;
 };
 
 enum KClass { K_QKV, K_O, K_GU, K_DOWN, K_HEAD, K_ATTN, K_NORM, K_ROPE, K_EMBED, K_SAMPLE, K_COUNT };
@@ -88,18 +94,30 @@ struct T3Engine {
     struct Group {
         hipStream_t stream = nullptr;
         uint16_t *h = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *act = nullptr, *logits = nullptr;
-        char *h_meta = nullptr, *d_meta = nullptr;
+        char *h_meta[2] = {nullptr, nullptr}, *d_meta = nullptr;     // host staging is double-buffered: step N+1 is built while N runs
         size_t meta_bytes = 0, meta_rows_off = 0;
-        Meta hm{}, dm{};
-        int* h_out_tok = nullptr;
+        Meta hm[2]{}, dm{};
+        int* h_out_tok[2] = {nullptr, nullptr};
+        hipEvent_t ev_done[2] = {nullptr, nullptr};
         int rcap = 0;              // row budget per step
         std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (M, n_sel) -> captured decode step
-        // per-step scratch
+    };
+    // One enqueued step: what the scheduler put on each group's stream, kept until its tokens are back.
+    struct StepRec {
         int M = 0, n_sel = 0, n_prefill_rows = 0, decode_rows = 0;
         double sum_ctx = 0;
         std::vector<Request*> sampled;
     };
+    struct Step {
+        std::vector<StepRec> g;
+        int buf = 0, M_all = 0, n_prefill_rows = 0, decode_rows = 0, n_sampled = 0;
+        double sum_ctx = 0;
+        std::chrono::steady_clock::time_point t_begin;
+    };
     std::vector<Group> groups;
+    unsigned step_seq = 0;
+    bool run_ahead = true;     // t3_run_steps / t3_run_until_done enqueue step N+1 before reading step N's tokens
+    std::chrono::steady_clock::time_point t_last_complete{};
     float* d_cond = nullptr;
     uint16_t* d_counts = nullptr;
     T3Sampling* d_sp = nullptr;
@@ -159,6 +177,7 @@ extern "C" int t3_create(const T3EngineConfig* cfg, T3Handle* out) {
         e->n_groups = std::max(1, std::min(g, std::min(8, cfg->max_seqs)));
         e->groups.resize(e->n_groups);
         if (const char* ev = getenv("T3_FUSE_ROPE")) e->fuse_rope = atoi(ev) != 0;
+        if (const char* ev = getenv("T3_RUN_AHEAD")) e->run_ahead = atoi(ev) != 0;
     }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail_create(T3_E_DEVICE, "hipStreamCreate failed"); }
     hipEventCreate(&e->ev0); hipEventCreate(&e->ev1); hipEventCreateWithFlags(&e->ev_admit, hipEventDisableTiming);
@@ -183,8 +202,11 @@ extern "C" int t3_destroy(T3Handle e) {
         for (auto& kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
         free_dev(g.h); free_dev(g.qkv); free_dev(g.qrot); free_dev(g.att); free_dev(g.act); free_dev(g.logits);
         free_dev(g.d_meta); free_dev(g.dm.out_tok);
-        if (g.h_meta) (void)hipHostFree(g.h_meta);
-        if (g.h_out_tok) (void)hipHostFree(g.h_out_tok);
+        for (int b = 0; b < 2; ++b) {
+            if (g.h_meta[b]) (void)hipHostFree(g.h_meta[b]);
+            if (g.h_out_tok[b]) (void)hipHostFree(g.h_out_tok[b]);
+            if (g.ev_done[b]) (void)hipEventDestroy(g.ev_done[b]);
+        }
         if (g.stream) (void)hipStreamDestroy(g.stream);
     }
     free_dev(e->d_cond); free_dev(e->d_counts); free_dev(e->d_sp); free_dev(e->d_dbg);
@@ -340,17 +362,21 @@ extern "C" int t3_finalize_weights(T3Handle e) {
         const size_t o_selr = carve(2 * Sg * 4), o_sel = carve(Sg * 16), o_rows = carve(R * (size_t)e->row_stride * 4);
         g.meta_rows_off = o_rows;
         g.meta_bytes = off;
-        HIP_TRY(hipHostMalloc((void**)&g.h_meta, g.meta_bytes, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void**)&g.d_meta, g.meta_bytes));
-        memset(g.h_meta, 0, g.meta_bytes);
         auto fill = [&](T3Engine::Meta& m, char* base) {
             m.sel_rows = (int*)(base + o_selr); m.sel = (int4*)(base + o_sel); m.rows = (int*)(base + o_rows); m.out_tok = nullptr;
         };
-        fill(g.hm, g.h_meta); fill(g.dm, g.d_meta);
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(hipHostMalloc((void**)&g.h_meta[b], g.meta_bytes, hipHostMallocDefault));
+            memset(g.h_meta[b], 0, g.meta_bytes);
+            fill(g.hm[b], g.h_meta[b]);
+            HIP_TRY(hipHostMalloc((void**)&g.h_out_tok[b], Sg * 4, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&g.ev_done[b], hipEventDisableTiming));
+        }
+        fill(g.dm, g.d_meta);
         int* dtok = nullptr;
         if ((rc = dalloc(e, &dtok, Sg, true))) return rc;
         g.dm.out_tok = dtok;
-        HIP_TRY(hipHostMalloc((void**)&g.h_out_tok, Sg * 4, hipHostMallocDefault));
     }
     if ((rc = dalloc(e, &e->d_cond, S * T3_COND_ROWS * D, true))) return rc;
     if ((rc = dalloc(e, &e->d_counts, S * VPAD, true))) return rc;
@@ -461,12 +487,12 @@ struct Prof {
 };
 
 // One group's kernel sequence for one step (eager, or recorded into a hipGraph by the caller).
-static int launch_step(T3Engine* e, T3Engine::Group& g) {
+static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr) {
     hipStream_t s = g.stream;
-    const int M = g.M, n_sel = g.n_sel;
+    const int M = sr.M, n_sel = sr.n_sel;
     {
         Prof p(e, K_EMBED, s);
-        EmbedArgs ea{g.dm.rows, e->row_stride, e->d_cond, e->text_emb, e->text_pos, e->speech_emb, e->speech_pos, g.h, M};
+        EmbedArgs ea{g.dm.rows, e->row_stride, e->d_cond, e->text_emb, e->text_pos, e->speech_emb, e->speech_pos, g.h, M, g.dm.out_tok};
         HIP_TRY(launch_embed(ea, s));
     }
     const size_t layer_elems = (size_t)e->n_blocks * KV_BLOCK_ELEMS;
@@ -476,7 +502,7 @@ static int launch_step(T3Engine* e, T3Engine::Group& g) {
         uint16_t* kvL = e->kv + (size_t)L * layer_elems;
         // 5 launches per layer: RMSNorm is folded into the qkv / gate-up GEMMs, the residual add into the o / down GEMMs
         { Prof p(e, K_QKV, s); GemmArgs a{g.h, (const uint4*)y.qkv, M, D, QKV, g.qkv, QKV, 4, y.ln1, nullptr}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s)); }
-        if (g.n_prefill_rows == 0 && e->fuse_rope) {
+        if (sr.n_prefill_rows == 0 && e->fuse_rope) {
             // decode-only step: every row is the newest position of its stream -> RoPE + KV write inside the attention kernel
             Prof p(e, K_ATTN, s);
             AttnArgs aa{nullptr, kvL, g.dm.rows, e->row_stride, g.att, M, max_chunks, g.qkv, kvL, e->cos_t, e->sin_t};
@@ -497,72 +523,83 @@ static int launch_step(T3Engine* e, T3Engine::Group& g) {
     return T3_OK;
 }
 
-extern "C" int t3_step(T3Handle e, T3StepResult* res) {
-    if (!e) return T3_E_INVALID;
-    if (!e->finalized) return e->fail(T3_E_STATE, "finalize_weights first");
-    (void)hipSetDevice(e->cfg.device_id);
-    T3StepResult local{}; if (!res) res = &local;
-    memset(res, 0, sizeof(*res));
+// Schedule one step and put it on the streams.  Does not wait for anything: a decode row whose input token is still
+// being sampled by the previous step refers to it by its index in the sampler's output array (EMB_SPEECH_PREV).
+static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
     int rc;
     if ((rc = admit(e))) return rc;
-
-    // ---- build rows per group: decode rows of every running utterance, then prefill rows within the group's budget
-    for (auto& g : e->groups) { g.M = g.n_sel = g.n_prefill_rows = g.decode_rows = 0; g.sum_ctx = 0; g.sampled.clear(); }
-    auto add_row = [&](T3Engine::Group& g, int stream, int pos, int kind, int a, int b) {
-        int* rec = g.hm.rows + (size_t)g.M * e->row_stride;
+    st = T3Engine::Step{};
+    st.g.resize(e->n_groups);
+    st.buf = (int)(e->step_seq++ & 1u);
+    const int buf = st.buf;
+    auto add_row = [&](int gi, int stream, int pos, int kind, int a, int b) {
+        T3Engine::StepRec& sr = st.g[gi];
+        int* rec = e->groups[gi].hm[buf].rows + (size_t)sr.M * e->row_stride;
         rec[0] = stream; rec[1] = pos; rec[2] = kind; rec[3] = a; rec[4] = b;
         memcpy(rec + ROW_HDR, &e->h_block_table[(size_t)stream * e->max_blocks], (size_t)e->max_blocks * 4);
-        ++g.M;
+        ++sr.M;
     };
+    // decode rows of every running utterance, then prefill rows within the group's budget
     for (int64_t id : e->running) {
         Request& r = e->reqs[id];
-        if (r.state != DECODE) continue;
-        auto& g = e->groups[r.slot % e->n_groups];
-        const int T = (int)r.prompt.size(), n = (int)r.out.size();
+        if (r.state != DECODE || r.n_sched >= r.limit) continue;       // limit reached: its last token is in flight
+        const int gi = r.slot % e->n_groups;
+        T3Engine::StepRec& sr = st.g[gi];
+        auto& hm = e->groups[gi].hm[buf];
+        const int T = (int)r.prompt.size(), n = r.n_sched;
         const int pos = T - 1 + n, spos = r.sp.pos_policy == 0 ? (n % 4100) : 0;
-        g.hm.sel_rows[2 * g.n_sel] = g.M;     add_row(g, 2 * r.slot, pos, EMB_SPEECH, r.out.back(), spos);
-        g.hm.sel_rows[2 * g.n_sel + 1] = g.M; add_row(g, 2 * r.slot + 1, pos, EMB_SPEECH, r.out.back(), spos);
-        g.hm.sel[g.n_sel] = make_int4(r.slot, n, 0, 0);
-        g.sum_ctx += 2.0 * (pos + 1);
-        g.sampled.push_back(&r); ++g.n_sel;
+        const bool known = (int)r.out.size() == n;
+        const int kind = known ? EMB_SPEECH : EMB_SPEECH_PREV, a = known ? r.out.back() : r.last_idx;
+        hm.sel_rows[2 * sr.n_sel] = sr.M;     add_row(gi, 2 * r.slot, pos, kind, a, spos);
+        hm.sel_rows[2 * sr.n_sel + 1] = sr.M; add_row(gi, 2 * r.slot + 1, pos, kind, a, spos);
+        hm.sel[sr.n_sel] = make_int4(r.slot, n, 0, 0);
+        sr.sum_ctx += 2.0 * (pos + 1);
+        r.last_idx = sr.n_sel; r.n_sched = n + 1;
+        sr.sampled.push_back(&r); ++sr.n_sel;
     }
-    for (auto& g : e->groups) g.decode_rows = g.M;
+    for (auto& sr : st.g) sr.decode_rows = sr.M;
     for (int64_t id : e->running) {
         Request& r = e->reqs[id];
         if (r.state != PREFILL) continue;
-        auto& g = e->groups[r.slot % e->n_groups];
+        const int gi = r.slot % e->n_groups;
+        T3Engine::StepRec& sr = st.g[gi];
+        auto& hm = e->groups[gi].hm[buf];
         const int T = (int)r.prompt.size();
-        const int chunk = std::min(T - r.n_prefilled, (g.rcap - g.M) / 2);
+        const int chunk = std::min(T - r.n_prefilled, (e->groups[gi].rcap - sr.M) / 2);
         if (chunk <= 0) continue;
         const int p0 = r.n_prefilled, p1 = p0 + chunk;
         for (int sI = 0; sI < 2; ++sI)
             for (int p = p0; p < p1; ++p) {
-                if (p < T3_COND_ROWS) add_row(g, 2 * r.slot + sI, p, EMB_COND, r.slot, p);
-                else if (p < T - 1) { if (sI == 0) add_row(g, 2 * r.slot, p, EMB_TEXT, r.prompt[p], p - T3_COND_ROWS); else add_row(g, 2 * r.slot + 1, p, EMB_ZERO, 0, 0); }
-                else add_row(g, 2 * r.slot + sI, p, EMB_SPEECH, 6561, 0);      // BOS: speech_emb[start] + speech_pos[0], t3.py:550-551
-                if (p == T - 1) g.hm.sel_rows[2 * g.n_sel + sI] = g.M - 1;
+                if (p < T3_COND_ROWS) add_row(gi, 2 * r.slot + sI, p, EMB_COND, r.slot, p);
+                else if (p < T - 1) { if (sI == 0) add_row(gi, 2 * r.slot, p, EMB_TEXT, r.prompt[p], p - T3_COND_ROWS); else add_row(gi, 2 * r.slot + 1, p, EMB_ZERO, 0, 0); }
+                else add_row(gi, 2 * r.slot + sI, p, EMB_SPEECH, 6561, 0);      // BOS: speech_emb[start] + speech_pos[0], t3.py:550-551
+                if (p == T - 1) hm.sel_rows[2 * sr.n_sel + sI] = sr.M - 1;
             }
-        r.n_prefilled = p1; g.n_prefill_rows += 2 * chunk;
-        if (p1 == T) { g.hm.sel[g.n_sel] = make_int4(r.slot, 0, 0, 0); g.sampled.push_back(&r); ++g.n_sel; }
+        r.n_prefilled = p1; sr.n_prefill_rows += 2 * chunk;
+        if (p1 == T) {
+            hm.sel[sr.n_sel] = make_int4(r.slot, 0, 0, 0);
+            r.state = DECODE; r.n_sched = 1; r.last_idx = sr.n_sel;
+            sr.sampled.push_back(&r); ++sr.n_sel;
+        }
     }
-    int M_all = 0, n_prefill_rows = 0, decode_rows = 0; double sum_ctx = 0;
-    for (auto& g : e->groups) { M_all += g.M; n_prefill_rows += g.n_prefill_rows; res->n_sampled += g.n_sel; decode_rows += g.decode_rows; sum_ctx += g.sum_ctx; }
-    res->n_rows = M_all; res->n_prefill_rows = n_prefill_rows;
-    if (M_all == 0) { res->n_running = (int)e->running.size(); res->n_waiting = (int)e->waiting.size(); return T3_OK; }
+    for (auto& sr : st.g) { st.M_all += sr.M; st.n_prefill_rows += sr.n_prefill_rows; st.n_sampled += sr.n_sel; st.decode_rows += sr.decode_rows; st.sum_ctx += sr.sum_ctx; }
+    st.t_begin = std::chrono::steady_clock::now();
+    if (st.M_all == 0) return T3_OK;
 
-    const auto t_begin = std::chrono::steady_clock::now();
-    for (auto& g : e->groups) {
-        if (g.M == 0) continue;
+    for (int gi = 0; gi < e->n_groups; ++gi) {
+        T3Engine::Group& g = e->groups[gi];
+        const T3Engine::StepRec& sr = st.g[gi];
+        if (sr.M == 0) continue;
         HIP_TRY(hipStreamWaitEvent(g.stream, e->ev_admit, 0));
-        HIP_TRY(hipMemcpyAsync(g.d_meta, g.h_meta, g.meta_rows_off + (size_t)g.M * e->row_stride * 4, hipMemcpyHostToDevice, g.stream));   // sel arrays + the used row records
-        const bool use_graph = !e->cfg.enforce_eager && !e->profile && g.n_prefill_rows == 0;
+        HIP_TRY(hipMemcpyAsync(g.d_meta, g.h_meta[buf], g.meta_rows_off + (size_t)sr.M * e->row_stride * 4, hipMemcpyHostToDevice, g.stream));   // sel arrays + the used row records
+        const bool use_graph = !e->cfg.enforce_eager && !e->profile && sr.n_prefill_rows == 0;
         if (use_graph) {
-            const auto key = std::make_pair(g.M, g.n_sel);
+            const auto key = std::make_pair(sr.M, sr.n_sel);
             auto it = g.graphs.find(key);
             if (it == g.graphs.end()) {
                 hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
                 HIP_TRY(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
-                const int lrc = launch_step(e, g);
+                const int lrc = launch_step(e, g, sr);
                 const hipError_t ce = hipStreamEndCapture(g.stream, &graph);
                 if (lrc) return lrc;
                 HIP_TRY(ce);
@@ -573,19 +610,32 @@ extern "C" int t3_step(T3Handle e, T3StepResult* res) {
             }
             HIP_TRY(hipGraphLaunch(it->second, g.stream));
         } else {
-            if ((rc = launch_step(e, g))) return rc;
+            int lrc;
+            if ((lrc = launch_step(e, g, sr))) return lrc;
         }
-        if (g.n_sel > 0) HIP_TRY(hipMemcpyAsync(g.h_out_tok, g.dm.out_tok, (size_t)g.n_sel * 4, hipMemcpyDeviceToHost, g.stream));
+        if (sr.n_sel > 0) HIP_TRY(hipMemcpyAsync(g.h_out_tok[buf], g.dm.out_tok, (size_t)sr.n_sel * 4, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipEventRecord(g.ev_done[buf], g.stream));
     }
-    for (auto& g : e->groups) if (g.M) HIP_TRY(hipStreamSynchronize(g.stream));
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    const bool decode_only = (n_prefill_rows == 0);
-    e->st.steps++; e->st.gpu_ms_total += ms; e->st.prefill_rows += n_prefill_rows; e->st.decode_rows += decode_rows;
+    return T3_OK;
+}
+
+// Wait for an enqueued step, account for it and hand its tokens to the requests.
+static int complete_step(T3Engine* e, T3Engine::Step& st, T3StepResult* res) {
+    res->n_rows = st.M_all; res->n_prefill_rows = st.n_prefill_rows; res->n_sampled = st.n_sampled;
+    if (st.M_all == 0) { res->n_running = (int)e->running.size(); res->n_waiting = (int)e->waiting.size(); return T3_OK; }
+    for (int gi = 0; gi < e->n_groups; ++gi) if (st.g[gi].M) HIP_TRY(hipEventSynchronize(e->groups[gi].ev_done[st.buf]));
+    const auto now = std::chrono::steady_clock::now();
+    // with a step running ahead, this step had the GPU to itself only since the previous one completed
+    const auto t0 = std::max(st.t_begin, e->t_last_complete);
+    e->t_last_complete = now;
+    const double ms = std::chrono::duration<double, std::milli>(now - t0).count();
+    const bool decode_only = (st.n_prefill_rows == 0);
+    e->st.steps++; e->st.gpu_ms_total += ms; e->st.prefill_rows += st.n_prefill_rows; e->st.decode_rows += st.decode_rows;
     if (decode_only) {
-        e->st.decode_steps++; e->st.gpu_ms_decode += ms; e->st.sum_ctx_decode += sum_ctx;
+        e->st.decode_steps++; e->st.gpu_ms_decode += ms; e->st.sum_ctx_decode += st.sum_ctx;
         // W + KV read + KV write + embedding rows, scaled to n_layers
         const double per_tok_stream = 2.0 * e->cfg.n_layers * H * HD * 2;
-        e->st.algo_bytes_decode += (double)e->weight_bytes_for_step() + per_tok_stream * sum_ctx + per_tok_stream * decode_rows + (decode_rows / 2) * 4096.0;
+        e->st.algo_bytes_decode += (double)e->weight_bytes_for_step() + per_tok_stream * st.sum_ctx + per_tok_stream * st.decode_rows + (st.decode_rows / 2) * 4096.0;
     }
     if (e->profile) {
         for (int k = 0; k < K_COUNT; ++k) {
@@ -595,11 +645,17 @@ extern "C" int t3_step(T3Handle e, T3StepResult* res) {
         }
     }
     // ---- host bookkeeping
-    for (auto& g : e->groups)
-        for (int i = 0; i < g.n_sel; ++i) {
-            Request& r = *g.sampled[i];
-            const int tok = g.h_out_tok[i];
-            r.out.push_back(tok); r.state = DECODE; e->st.tokens_generated++;
+    for (int gi = 0; gi < e->n_groups; ++gi) {
+        const T3Engine::StepRec& sr = st.g[gi];
+        const int* toks = e->groups[gi].h_out_tok[st.buf];
+        for (int i = 0; i < sr.n_sel; ++i) {
+            Request& r = *sr.sampled[i];
+            if (r.state == FINISHED) {       // row scheduled before its stop token was seen: drop the result, free the slot now
+                if (r.zombie) { r.zombie = false; release_slot(e, r); }
+                continue;
+            }
+            const int tok = toks[i];
+            r.out.push_back(tok); e->st.tokens_generated++;
             int fin = 0;
             if (!r.sp.ignore_eos && tok == r.sp.stop_token) fin = 1;
             else if ((int)r.out.size() >= r.limit) fin = 2;
@@ -607,37 +663,70 @@ extern "C" int t3_step(T3Handle e, T3StepResult* res) {
                 r.state = FINISHED; r.finish_reason = fin;
                 if (res->n_finished < 64) res->finished_ids[res->n_finished] = r.id;
                 res->n_finished++;
-                release_slot(e, r);
+                if (r.n_sched > (int)r.out.size()) r.zombie = true;     // the step running ahead still uses its slot and KV blocks
+                else release_slot(e, r);
             }
         }
+    }
     if (res->n_finished) e->running.erase(std::remove_if(e->running.begin(), e->running.end(), [&](int64_t id) { return e->reqs[id].state == FINISHED; }), e->running.end());
     res->n_running = (int)e->running.size(); res->n_waiting = (int)e->waiting.size();
     return T3_OK;
 }
 
-extern "C" int t3_run_until_done(T3Handle e) {
+static int check_ready(T3Engine* e) {
     if (!e) return T3_E_INVALID;
-    T3StepResult r;
-    while (t3_num_unfinished(e) > 0) {
-        int rc = t3_step(e, &r);
-        if (rc) return rc;
-        if (r.n_rows == 0) return e->fail(T3_E_NOMEM, "scheduler stalled: waiting requests cannot be admitted");
-    }
+    if (!e->finalized) return e->fail(T3_E_STATE, "finalize_weights first");
+    (void)hipSetDevice(e->cfg.device_id);
     return T3_OK;
 }
 
-extern "C" int t3_run_steps(T3Handle e, int32_t n, int32_t* done) {
-    if (!e) return T3_E_INVALID;
-    T3StepResult r;
-    int k = 0;
-    for (; k < n && t3_num_unfinished(e) > 0; ++k) {
-        int rc = t3_step(e, &r);
-        if (rc) { if (done) *done = k; return rc; }
-        if (r.n_rows == 0) break;
-    }
-    if (done) *done = k;
-    return T3_OK;
+extern "C" int t3_step(T3Handle e, T3StepResult* res) {
+    int rc;
+    if ((rc = check_ready(e))) return rc;
+    T3StepResult local{}; if (!res) res = &local;
+    memset(res, 0, sizeof(*res));
+    T3Engine::Step st;
+    if ((rc = enqueue_step(e, st))) return rc;
+    return complete_step(e, st, res);
 }
+
+// The step loop of t3_run_steps / t3_run_until_done.  With run-ahead, step N+1 is scheduled and enqueued before the
+// host waits for step N, so the device never idles across the token read-back and the scheduler.  An utterance whose
+// stop token turns up in step N has one wasted row pair in step N+1; its token stream is unaffected.
+static int run_loop(T3Engine* e, int64_t n, int32_t* done, bool stall_is_error) {
+    int rc;
+    if ((rc = check_ready(e))) return rc;
+    const bool ahead_ok = e->run_ahead && !e->profile && !e->cfg.debug_logits;
+    T3Engine::Step cur, nxt;
+    T3StepResult r;
+    bool have = false;
+    int64_t k = 0;
+    rc = T3_OK;
+    while (k < n && (have || t3_num_unfinished(e) > 0)) {
+        if (!have) {
+            if ((rc = enqueue_step(e, cur))) break;
+            if (cur.M_all == 0) { if (stall_is_error) rc = e->fail(T3_E_NOMEM, "scheduler stalled: waiting requests cannot be admitted"); break; }
+            have = true;
+        }
+        bool ahead = false;
+        if (ahead_ok && k + 1 < n) {
+            if ((rc = enqueue_step(e, nxt))) { memset(&r, 0, sizeof(r)); (void)complete_step(e, cur, &r); have = false; ++k; break; }
+            ahead = nxt.M_all > 0;
+        }
+        memset(&r, 0, sizeof(r));
+        rc = complete_step(e, cur, &r);
+        have = false; ++k;
+        if (ahead) { std::swap(cur, nxt); have = true; }
+        if (rc) break;
+    }
+    if (have) { memset(&r, 0, sizeof(r)); const int rc2 = complete_step(e, cur, &r); ++k; if (!rc) rc = rc2; }
+    if (done) *done = (int32_t)k;
+    return rc;
+}
+
+extern "C" int t3_run_until_done(T3Handle e) { return run_loop(e, INT64_MAX, nullptr, true); }
+
+extern "C" int t3_run_steps(T3Handle e, int32_t n, int32_t* done) { return run_loop(e, n, done, false); }
 
 extern "C" int t3_get_output(T3Handle e, int64_t req_id, int32_t* ids, int32_t* n, int32_t* finish_reason) {
     if (!e || !n) return T3_E_INVALID;

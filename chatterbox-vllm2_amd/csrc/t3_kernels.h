@@ -55,8 +55,10 @@ struct EmbedArgs {
     const uint16_t *text_emb, *text_pos, *speech_emb, *speech_pos;
     uint16_t* h;               // [rows][1024]
     int rows;
+    const int* prev_tok;       // the sampler's output array of the previous step (EMB_SPEECH_PREV)
 };
-enum EmbedKind { EMB_COND = 0 /*a=slot,b=idx*/, EMB_TEXT = 1 /*a=id,b=pos*/, EMB_ZERO = 2, EMB_SPEECH = 3 /*a=id,b=pos*/ };
+enum EmbedKind { EMB_COND = 0 /*a=slot,b=idx*/, EMB_TEXT = 1 /*a=id,b=pos*/, EMB_ZERO = 2, EMB_SPEECH = 3 /*a=id,b=pos*/,
+                 EMB_SPEECH_PREV = 4 /*a=index into prev_tok,b=pos*/ };
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
 
 struct RopeArgs {

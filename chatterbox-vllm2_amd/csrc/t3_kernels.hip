@@ -357,7 +357,8 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
     const int* rec = a.rowrec + (size_t)row * a.row_stride;
-    const int4 d = make_int4(rec[2], rec[3], rec[4], 0);
+    int4 d = make_int4(rec[2], rec[3], rec[4], 0);
+    if (d.x == EMB_SPEECH_PREV) { d.x = EMB_SPEECH; d.y = a.prev_tok[d.y]; }   // token sampled by the step still in flight when this one was scheduled
     uint4* out = reinterpret_cast<uint4*>(a.h + (size_t)row * D);
     if (d.x == EMB_ZERO) {
         out[lane] = make_uint4(0, 0, 0, 0); out[64 + lane] = make_uint4(0, 0, 0, 0);
@@ -640,36 +641,67 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
 constexpr int SPT = 33;                 // elements per thread in contiguous ownership: 256*33 >= 8194
 constexpr int SLOTS = 256 * SPT;
 
-__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int off) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, off), hi = __shfl_xor((uint32_t)(v >> 32), off);
+// Wave-level reductions and scans on the DPP cross-lane path (a ds_bpermute butterfly costs ~0.2 us per level here;
+// the sampler is a chain of such reductions).  All operands are integers (or a float max), so order is immaterial.
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {     // bound_ctrl: lanes without a source read 0
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, true);
     return ((unsigned long long)hi << 32) | lo;
 }
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_SHR = 0x110;
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+    v += dpp_u64<DPP_XOR1>(v); v += dpp_u64<DPP_XOR2>(v); v += dpp_u64<DPP_HALF_MIRROR>(v); v += dpp_u64<DPP_MIRROR>(v);   // row of 16
+    return readlane_u64(v, 0) + readlane_u64(v, 16) + readlane_u64(v, 32) + readlane_u64(v, 48);
+}
+__device__ __forceinline__ unsigned long long max_u64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    v = max_u64(v, dpp_u64<DPP_XOR1>(v)); v = max_u64(v, dpp_u64<DPP_XOR2>(v));
+    v = max_u64(v, dpp_u64<DPP_HALF_MIRROR>(v)); v = max_u64(v, dpp_u64<DPP_MIRROR>(v));
+    return max_u64(max_u64(readlane_u64(v, 0), readlane_u64(v, 16)), max_u64(readlane_u64(v, 32), readlane_u64(v, 48)));
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ unsigned long long wave_scan_u64(unsigned long long v, int lane) {
+    v += dpp_u64<DPP_SHR + 1>(v); v += dpp_u64<DPP_SHR + 2>(v); v += dpp_u64<DPP_SHR + 4>(v); v += dpp_u64<DPP_SHR + 8>(v);  // within rows of 16
+    const unsigned long long t0 = readlane_u64(v, 15), t1 = readlane_u64(v, 31), t2 = readlane_u64(v, 47);
+    return v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+}
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* scr) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += shfl_xor_u64(v, off);
+    v = wave_sum_u64(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
     __syncthreads();
     return scr[0] + scr[1] + scr[2] + scr[3];
 }
 __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, unsigned long long* scr) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const unsigned long long o = shfl_xor_u64(v, off); v = o > v ? o : v; }
+    v = wave_max_u64(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
     __syncthreads();
-    unsigned long long r = scr[0];
-    r = scr[1] > r ? scr[1] : r; r = scr[2] > r ? scr[2] : r; r = scr[3] > r ? scr[3] : r;
-    return r;
+    return max_u64(max_u64(scr[0], scr[1]), max_u64(scr[2], scr[3]));
 }
+// max over finite-or-minus-infinity floats through the order-preserving integer key
 __device__ __forceinline__ float block_max_f32(float v, unsigned long long* scr) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    uint32_t b = __float_as_uint(v + 0.0f);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    b = (uint32_t)block_max_u64(b, scr);
+    b = (b & 0x80000000u) ? (b & 0x7fffffffu) : ~b;
+    return __uint_as_float(b);
+}
+// inclusive prefix sum over the 256 threads of the workgroup; *total = sum over all
+__device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v, unsigned long long* scr, unsigned long long* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_scan_u64(v, lane);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) reinterpret_cast<float*>(scr)[threadIdx.x >> 6] = v;
+    if (lane == 63) scr[wave] = v;
     __syncthreads();
-    const float* f = reinterpret_cast<const float*>(scr);
-    return fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3]));
+    const unsigned long long s0 = scr[0], s1 = scr[1], s2 = scr[2], s3 = scr[3];
+    *total = s0 + s1 + s2 + s3;
+    return v + (wave >= 1 ? s0 : 0) + (wave >= 2 ? s1 : 0) + (wave >= 3 ? s2 : 0);
 }
 
 __device__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -684,7 +716,16 @@ __device__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+#ifdef T3_SAMPLER_CLK      // diagnostic build only: phase timestamps (100 MHz ticks) overwrite dbg[0..] at exit
+#define T3_CLK(i) clk[i] = wall_clock64()
+#else
+#define T3_CLK(i)
+#endif
 __global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
+#ifdef T3_SAMPLER_CLK
+    unsigned long long clk[12] = {0};
+#endif
+    T3_CLK(0);
     extern __shared__ __attribute__((aligned(16))) unsigned long long sw[];   // [SLOTS] weights | [8] scratch | [256] partial sums
     unsigned long long* scr = sw + SLOTS;
     unsigned long long* psum = scr + 8;
@@ -697,130 +738,197 @@ __global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
     uint16_t* counts = a.counts + (size_t)slot * VPAD;
     float* xs = reinterpret_cast<float*>(sw);     // phase A: xs[v] (fp32) lives in the low half of slot v
 
-    // ---- phase A (strided, coalesced): CFG, penalties
+    // ---- phase A: CFG, penalties.  16-byte loads of 8 logits / counts, all issued before the first use
+    // (a scalar loop here is a chain of dependent memory latencies, not bandwidth).
     const bool greedy = sp.temperature < 1e-5f;
     float mx = -INFINITY;
     unsigned long long best = 0;
-    for (int v = tid; v < SLOTS; v += 256) {
-        float x = -INFINITY;
-        if (v < V) {
-            const float c = bf2f(lc[v]), un = bf2f(lu[v]);
-            const float d = rbf(c - un);
-            const float e = rbf(a.cfg * d);
-            x = rbf(c + e);
-            if (a.dbg) a.dbg[(size_t)slot * V + v] = x;
-            const uint32_t cnt = counts[v];
-            if (cnt > 0) {
-                if (sp.repetition_penalty != 1.0f) x = (x > 0.0f) ? x / sp.repetition_penalty : x * sp.repetition_penalty;
-                x = x - sp.frequency_penalty * (float)cnt;
-                x = x - sp.presence_penalty;
-            }
-            if (greedy) {
-                const float xz = x + 0.0f;                       // -0 -> +0 so that the key order equals '>' on floats
-                uint32_t b = __float_as_uint(xz);
-                b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-                const unsigned long long key = ((unsigned long long)b << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)v);
-                best = key > best ? key : best;
-            } else {
-                x = x / sp.temperature;
-                mx = fmaxf(mx, x);
-            }
+    constexpr int NVEC = VPAD / 8, VIT = (NVEC + 255) / 256;
+    static_assert(VPAD % 8 == 0 && SLOTS >= VPAD, "sampler vector layout");
+    uint4 c4[VIT], u4[VIT], n4[VIT];
+#pragma unroll
+    for (int k = 0; k < VIT; ++k) {
+        const int vi = tid + 256 * k;
+        if (vi < NVEC) {
+            c4[k] = reinterpret_cast<const uint4*>(lc)[vi];
+            u4[k] = reinterpret_cast<const uint4*>(lu)[vi];
+            n4[k] = reinterpret_cast<const uint4*>(counts)[vi];
         }
-        xs[2 * v] = x;
     }
+    for (int v = VPAD + tid; v < SLOTS; v += 256) xs[2 * v] = -INFINITY;
+    T3_CLK(1);
+#pragma unroll
+    for (int k = 0; k < VIT; ++k) {
+        const int vi = tid + 256 * k;
+        if (vi >= NVEC) continue;
+        const uint32_t cw[4] = {c4[k].x, c4[k].y, c4[k].z, c4[k].w}, uw[4] = {u4[k].x, u4[k].y, u4[k].z, u4[k].w},
+                       nw[4] = {n4[k].x, n4[k].y, n4[k].z, n4[k].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int v = vi * 8 + j;
+            const int sh = (j & 1) * 16;
+            float x = -INFINITY;
+            if (v < V) {
+                const float c = bf2f((uint16_t)(cw[j >> 1] >> sh)), un = bf2f((uint16_t)(uw[j >> 1] >> sh));
+                const float d = rbf(c - un);
+                const float e = rbf(a.cfg * d);
+                x = rbf(c + e);
+                if (a.dbg) a.dbg[(size_t)slot * V + v] = x;
+                const uint32_t cnt = (nw[j >> 1] >> sh) & 0xFFFFu;
+                if (cnt > 0) {
+                    if (sp.repetition_penalty != 1.0f) x = (x > 0.0f) ? x / sp.repetition_penalty : x * sp.repetition_penalty;
+                    x = x - sp.frequency_penalty * (float)cnt;
+                    x = x - sp.presence_penalty;
+                }
+                if (greedy) {
+                    const float xz = x + 0.0f;                       // -0 -> +0 so that the key order equals '>' on floats
+                    uint32_t b = __float_as_uint(xz);
+                    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+                    const unsigned long long key = ((unsigned long long)b << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)v);
+                    best = key > best ? key : best;
+                } else {
+                    x = x / sp.temperature;
+                    mx = fmaxf(mx, x);
+                }
+            }
+            xs[2 * v] = x;
+        }
+    }
+    T3_CLK(2);
     int token;
     if (greedy) {
         best = block_max_u64(best, scr);
         token = (int)(0xFFFFFFFFu - (uint32_t)best);
     } else {
         mx = block_max_f32(mx, scr);
-        // ---- weights (same strided ownership as phase A, so no barrier needed before overwriting)
-        for (int v = tid; v < SLOTS; v += 256) {
+        // ---- weights (block_max above is the barrier between writing xs and overwriting it slot by slot)
+#pragma unroll 11
+        for (int k = 0; k < SPT; ++k) {
+            const int v = tid + 256 * k;
             const float x = xs[2 * v];
             unsigned long long w = 0;
             if (v < V) w = (unsigned long long)(t3_expf(x - mx) * 4294967296.0f);
             sw[v] = w;
         }
         __syncthreads();
+        T3_CLK(3);
+        // From here on a thread owns SPT consecutive vocabulary entries and keeps them in registers.
         const int v0 = tid * SPT;
+        unsigned long long wr[SPT];
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) wr[i] = sw[v0 + i];
         unsigned long long wmax = 0;
-        for (int i = 0; i < SPT; ++i) { const unsigned long long w = sw[v0 + i]; wmax = w > wmax ? w : wmax; }
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) wmax = max_u64(wmax, wr[i]);
         wmax = block_max_u64(wmax, scr);
         if (sp.min_p > 0.0f) {
             const double thr = (double)sp.min_p * (double)wmax;
-            for (int i = 0; i < SPT; ++i) if ((double)sw[v0 + i] < thr) sw[v0 + i] = 0;
+#pragma unroll
+            for (int i = 0; i < SPT; ++i) if ((double)wr[i] < thr) wr[i] = 0;
         }
         if (sp.top_k > 0 && sp.top_k < V) {
             unsigned long long lo = 0, hi = wmax;
             while (lo < hi) {
                 const unsigned long long mid = lo + (hi - lo + 1) / 2;
                 unsigned long long cnt = 0;
-                for (int i = 0; i < SPT; ++i) cnt += (sw[v0 + i] >= mid) ? 1 : 0;
+#pragma unroll
+                for (int i = 0; i < SPT; ++i) cnt += (wr[i] >= mid) ? 1 : 0;
                 cnt = block_sum_u64(cnt, scr);
                 if (cnt >= (unsigned long long)sp.top_k) lo = mid; else hi = mid - 1;
             }
-            for (int i = 0; i < SPT; ++i) if (sw[v0 + i] < lo) sw[v0 + i] = 0;
+#pragma unroll
+            for (int i = 0; i < SPT; ++i) if (wr[i] < lo) wr[i] = 0;
         }
+        T3_CLK(4);
         if (sp.top_p < 1.0f) {
             unsigned long long W = 0;
-            for (int i = 0; i < SPT; ++i) W += sw[v0 + i];
+#pragma unroll
+            for (int i = 0; i < SPT; ++i) W += wr[i];
             W = block_sum_u64(W, scr);
             const unsigned long long Tm = (unsigned long long)((1.0 - (double)sp.top_p) * (double)W);
-            unsigned long long lo = 0, hi = wmax;
-            while (lo < hi) {
-                const unsigned long long mid = lo + (hi - lo + 1) / 2;
-                unsigned long long s = 0;
-                for (int i = 0; i < SPT; ++i) { const unsigned long long w = sw[v0 + i]; s += (w < mid) ? w : 0; }
-                s = block_sum_u64(s, scr);
-                if (s <= Tm) lo = mid; else hi = mid - 1;
+            // lo = max{mid : sum of weights < mid is <= Tm} is the weight value at which the ascending cumulative
+            // mass first exceeds Tm.  Radix descent on the value: one round over the octaves, then 6 bits per
+            // round; per round an LDS histogram of masses (exact integer sums, so order-free) and a 64-bin
+            // wave scan that every wave repeats for itself.
+            T3_CLK(5);
+            unsigned long long* hist = psum;                 // [64]
+            const int lane = tid & 63;
+            unsigned long long lo = wmax, base = 0, prefix = 0;
+            int nb = -1;                                     // bits of the value still undetermined; -1: octave round
+            for (;;) {
+                __syncthreads();
+                if (tid < 64) hist[tid] = 0;
+                __syncthreads();
+                if (nb < 0) {
+#pragma unroll
+                    for (int i = 0; i < SPT; ++i) if (wr[i]) atomicAdd(&hist[64 - __clzll((long long)wr[i])], wr[i]);
+                } else {
+                    const int shift = nb > 6 ? nb - 6 : 0;
+                    const unsigned long long msk = (1ull << (nb - shift)) - 1;
+#pragma unroll
+                    for (int i = 0; i < SPT; ++i) if ((wr[i] >> nb) == prefix) atomicAdd(&hist[(wr[i] >> shift) & msk], wr[i]);
+                }
+                __syncthreads();
+                const unsigned long long own = hist[lane];
+                const unsigned long long c = wave_scan_u64(own, lane);      // inclusive scan over the 64 bins
+                const unsigned long long over = __ballot(base + c > Tm);
+                if (!over) break;                            // only in the octave round, when Tm == W: lo = wmax
+                const int b = __ffsll((long long)over) - 1;
+                base += readlane_u64(c - own, b);
+                if (nb < 0) { prefix = 1; nb = b - 1; }
+                else { const int shift = nb > 6 ? nb - 6 : 0; prefix = (prefix << (nb - shift)) | (unsigned long long)b; nb = shift; }
+                if (nb == 0) { lo = prefix; break; }
             }
+            T3_CLK(6);
             if (lo > 0) {
-                unsigned long long below = 0, ties = 0;
-                for (int i = 0; i < SPT; ++i) { const unsigned long long w = sw[v0 + i]; below += (w < lo) ? w : 0; ties += (w == lo) ? 1 : 0; }
-                const unsigned long long my_ties = ties;
+                unsigned long long below = 0, my_ties = 0;
+#pragma unroll
+                for (int i = 0; i < SPT; ++i) { below += (wr[i] < lo) ? wr[i] : 0; my_ties += (wr[i] == lo) ? 1 : 0; }
                 below = block_sum_u64(below, scr);
-                ties = block_sum_u64(ties, scr);
+                unsigned long long ties;
+                const unsigned long long incl = block_scan_u64(my_ties, scr, &ties);
                 unsigned long long r = (Tm - below) / lo;
                 if (lo == wmax && r > ties - 1) r = ties - 1;
                 if (r > ties) r = ties;
                 // ties are dropped highest index first
-                __syncthreads();
-                psum[tid] = my_ties;
-                __syncthreads();
-                unsigned long long above = 0;
-                if (r > 0) for (int t = tid + 1; t < 256; ++t) above += psum[t];
+                unsigned long long above = ties - incl;          // ties owned by higher threads
+#pragma unroll
                 for (int i = SPT - 1; i >= 0; --i) {
-                    const unsigned long long w = sw[v0 + i];
-                    if (w < lo) sw[v0 + i] = 0;
-                    else if (w == lo) { if (above < r) sw[v0 + i] = 0; ++above; }
+                    if (wr[i] < lo) wr[i] = 0;
+                    else if (wr[i] == lo) { if (above < r) wr[i] = 0; ++above; }
                 }
             }
         }
+        T3_CLK(7);
         // ---- draw
         unsigned long long mine = 0;
-        for (int i = 0; i < SPT; ++i) mine += sw[v0 + i];
-        __syncthreads();
-        psum[tid] = mine;
-        __syncthreads();
-        unsigned long long excl = 0, Wk = 0;
-        for (int t = 0; t < 256; ++t) { const unsigned long long p = psum[t]; if (t < tid) excl += p; Wk += p; }
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) mine += wr[i];
+        unsigned long long Wk;
+        const unsigned long long excl = block_scan_u64(mine, scr, &Wk) - mine;
+        T3_CLK(8);
         uint32_t rnd[4];
         philox4x32_10(step, (uint32_t)sp.uid, (uint32_t)(sp.uid >> 32), 0u, (uint32_t)sp.seed, (uint32_t)(sp.seed >> 32), rnd);
         const unsigned long long uu = ((unsigned long long)rnd[1] << 32) | rnd[0];
         const unsigned long long target = __umul64hi(uu, Wk);
         int* tokp = reinterpret_cast<int*>(scr + 4);
         if (mine > 0 && target >= excl && target < excl + mine) {
-            unsigned long long cum = excl; int found = v0;
-            for (int i = 0; i < SPT; ++i) { const unsigned long long w = sw[v0 + i]; if (w > 0) { cum += w; found = v0 + i; if (cum > target) break; } }
+            unsigned long long cum = excl; int found = -1;      // first entry whose running mass passes the target
+#pragma unroll
+            for (int i = 0; i < SPT; ++i) { cum += wr[i]; if (found < 0 && cum > target) found = v0 + i; }
             *tokp = found;
         }
         __syncthreads();
         token = *tokp;
+        T3_CLK(9);
     }
     if (tid == 0) {
         a.out_tok[u] = token;
         const uint16_t cnt = counts[token];
         if (cnt < 65535) counts[token] = cnt + 1;
+#ifdef T3_SAMPLER_CLK
+        if (a.dbg) for (int i = 0; i < 10; ++i) a.dbg[(size_t)slot * V + i] = (float)(clk[i] - clk[0]);
+#endif
     }
 }
 hipError_t prepare_kernels() {

@@ -112,6 +112,37 @@ def test_groups_and_graph_replay_do_not_change_ids(E, oracle, tiny_weights, tiny
     eng.close()
 
 
+@pytest.mark.parametrize("run_ahead", ["1", "0"])
+def test_run_ahead_with_stop_tokens(E, oracle, tiny_weights, tiny_oracle, cond, run_ahead, monkeypatch):
+    """The C++ step loop schedules step N+1 before it has read step N's tokens (DESIGN.md "Run-ahead"): an utterance
+    that emits its stop id has one discarded row pair in flight and its slot is freed one step later.  Streams must
+    still end exactly at the stop id, later admissions must reuse the slots, and every KV block must come back."""
+    monkeypatch.setenv("T3_RUN_AHEAD", run_ahead)
+    eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=400, max_seqs=4, kv_bytes=1 << 29, enforce_eager=False)
+    eng.load_tensors(tiny_weights); eng.finalize()
+    reqs = []
+    for i in range(10):
+        prompt = make_prompt(4 + 5 * i, seed=70 + i)
+        kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=11, uid=i, max_tokens=30)
+        ref, _ = tiny_oracle.generate(prompt, cond, oracle.make_sampling(ignore_eos=True, **kw), max_model_len=400)
+        stop = ref[3 + 2 * i] if i < 9 else 8193       # stops at different steps; the last one runs into max_tokens
+        want, _ = tiny_oracle.generate(prompt, cond, oracle.make_sampling(stop_token=stop, **kw), max_model_len=400)
+        assert want == ref[: ref.index(stop) + 1] if stop in ref else want == ref
+        reqs.append((i, want, 1 if stop in ref else 2))
+        eng.add_request(i, prompt, cond, E.make_sampling(stop_token=stop, **kw))
+    done = 0
+    while eng.num_unfinished():                        # bounded calls: the loop must drain its in-flight step at every return
+        n = eng.run_steps(7)
+        assert n > 0
+        done += n
+    for i, want, reason in reqs:
+        got, fr = eng.get_output(i)
+        assert [t - 2500 for t in got] == want and fr == reason, f"utterance {i} (run_ahead={run_ahead})"
+    st = eng.stats()
+    assert st.kv_blocks_free == st.kv_blocks_total
+    eng.close()
+
+
 def test_chunked_prefill_equals_whole(E, tiny_weights, cond):
     """A row budget smaller than one prompt forces the prompt through several steps; ids must not change."""
     outs = []
