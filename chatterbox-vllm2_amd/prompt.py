@@ -56,6 +56,18 @@ def find_tokenizer_file(kind: str, model_dir: Optional[str] = None, explicit: Op
     return None
 
 
+def _korean_normalize(text: str) -> str:
+    """Hangul syllables -> conjoining jamo (initial 0x1100+, medial 0x1161+, final 0x11A7+), then strip."""
+    out = []
+    for ch in text:
+        if "\uac00" <= ch <= "\ud7af":
+            base = ord(ch) - 0xAC00
+            out.append(chr(0x1100 + base // 588) + chr(0x1161 + (base % 588) // 28) + (chr(0x11A7 + base % 28) if base % 28 else ""))
+        else:
+            out.append(ch)
+    return "".join(out).strip()
+
+
 class TextTokenizer:
     """kind = "EnTokenizer" | "MtlTokenizer" (the names the reference registers, t3/__init__.py:6-7)."""
 
@@ -79,9 +91,11 @@ class TextTokenizer:
             language_id = text.split("<")[1].split(">")[0]
             text = text.split(">")[1]
         text = normalize("NFKD", text.lower())                               # mtltokenizer.py:284-298
-        if language_id in ("zh", "ja", "he", "ko", "ru"):
-            # the reference runs Cangjie / kakasi / dicta / jamo / stresser here (mtltokenizer.py:311-320);
-            # those need packages or downloads that are not part of the T3 hot path.
+        if language_id == "ko":
+            text = _korean_normalize(text)                                   # mtltokenizer.py:106-125, 317-318
+        elif language_id in ("zh", "ja", "he", "ru"):
+            # the reference runs Cangjie / kakasi / dicta / a stress marker here (mtltokenizer.py:311-320); those need
+            # packages or a download that this image does not have, so these four languages are not pinned.
             import warnings
             warnings.warn(f"language-specific normaliser for {language_id!r} is not applied")
         if language_id:

@@ -106,6 +106,35 @@ def g7_tokenizer():
     print("G7 tokenizer: en", len(out["en_english_ids"]), "en/mtl", len(out["en_mtl_ids"]), "es/mtl", len(out["es_mtl_ids"]))
 
 
+def g7b_tokenizer_cases():
+    """ids produced by the reference's OWN tokenizer classes (entokenizer.py / mtltokenizer.py imported as leaf modules,
+    their vocabulary JSON files read in place) through PreTrainedTokenizer.encode, the call vLLM makes on a prompt string.
+    Languages whose normaliser needs an absent package or a download (zh, ja, he, ru) are not covered."""
+    import importlib
+    os.environ.setdefault("HF_HUB_OFFLINE", "1")          # the Cangjie table download fails fast; the class tolerates that
+    import_reference_leaf_modules()
+    en_mod = importlib.import_module("chatterbox_vllm.models.t3.entokenizer")
+    mtl_mod = importlib.import_module("chatterbox_vllm.models.t3.mtltokenizer")
+    en = en_mod.EnTokenizer.from_pretrained()
+    mtl = mtl_mod.MTLTokenizer.from_pretrained()
+    en_texts = [EN_TEXT, "Hello, world!", "  two  spaces  and trailing ", "UPPER lower MiXeD 123 4.5%", "Don't stop -- believing; it's 9:30?",
+                "naïve café déjà vu", "a", "", "tabs\tand\nnewlines", "quotes \"double\" and 'single' (parens) [brackets]",
+                "emoji \U0001F600 and symbols © ™ € £", "x" * 300]
+    mtl_texts = [("en", EN_TEXT), ("es", ES_TEXT), ("fr", "Où est la bibliothèque, s'il vous plaît ?"), ("de", "Größe und Straße: Äpfel, Öl, Übung."),
+                 ("it", "Perché no? È così!"), ("pt", "Não há ação sem coração."), ("ko", "안녕하세요, 만나서 반갑습니다."),
+                 ("en", "a > b is dropped after the second bracket"), ("EN", "Upper-case language tag"), (None, "No language tag at all"),
+                 ("en", ""), ("pl", "Zażółć gęślą jaźń"), ("tr", "İstanbul'da ılık bir gün"), ("hi", "नमस्ते दुनिया"), ("ar", "مرحبا بالعالم")]
+    out = {"en": [], "mtl": []}
+    for t in en_texts:
+        prompt = "[START]" + t + "[STOP]"                                   # tts.py:435
+        out["en"].append({"prompt": prompt, "ids": [int(i) for i in en.encode(prompt)]})
+    for lang, t in mtl_texts:
+        prompt = (f"<{lang}>" if lang else "") + "[START]" + t + "[STOP]"    # tts.py:441
+        out["mtl"].append({"prompt": prompt, "ids": [int(i) for i in mtl.encode(prompt)]})
+    json.dump(out, open(os.path.join(HERE, "tokenizer_cases.json"), "w"), indent=1, ensure_ascii=False)
+    print("G7b tokenizer cases:", len(out["en"]), "en,", len(out["mtl"]), "mtl")
+
+
 def g6_streams():
     from oracle import oracle as O
     from chatterbox_vllm2_amd.prompt import assemble_prompt_ids
@@ -175,9 +204,10 @@ def g8_postfilter():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g7", "g6", "g8"]
+    which = sys.argv[1:] or ["g1", "g3", "g7", "g7b", "g6", "g8"]
     if "g1" in which: g1_cond_enc()
     if "g3" in which: g3_rope()
     if "g7" in which: g7_tokenizer()
+    if "g7b" in which: g7b_tokenizer_cases()
     if "g6" in which: g6_streams()
     if "g8" in which: g8_postfilter()

@@ -45,6 +45,31 @@ def test_tokenizer_goldens():
         assert 255 not in tok["en_mtl_ids"]
 
 
+def test_tokenizer_matches_reference_classes():
+    """prompt string -> ids.  tests/golden/tokenizer_cases.json holds the ids the reference's own
+    EnTokenizer / MTLTokenizer classes produced (make_golden.py g7b).  The vocabulary JSON files are the reference's data
+    and stay there, so the comparison itself runs where they are present (the build container); elsewhere only the
+    fixture's own invariants are checked.  zh / ja / he / ru normalisers need absent packages: parity unpinned for those."""
+    cases = json.load(open(os.path.join(G, "tokenizer_cases.json")))
+    assert len(cases["en"]) >= 10 and len(cases["mtl"]) >= 10
+    for c in cases["en"]:
+        assert c["ids"][0] == 255 and c["ids"][-1] == 0                       # [START] ... [STOP]
+    for c in cases["mtl"]:
+        assert 255 not in c["ids"]                                            # lower-cased "[start]" is spelled out in pieces
+    second = next(c for c in cases["mtl"] if "a > b" in c["prompt"])
+    assert len(second["ids"]) == 8                                            # text.split('>')[1]: everything after the 2nd '>' is dropped
+    ref = "/root/reference/src/chatterbox_vllm/models/t3"
+    if not os.path.exists(ref):
+        pytest.skip("reference vocabulary files not present on this machine")
+    from chatterbox_vllm2_amd.prompt import TextTokenizer
+    en = TextTokenizer("EnTokenizer", os.path.join(ref, "tokenizer.json"))
+    mtl = TextTokenizer("MtlTokenizer", os.path.join(ref, "grapheme_mtl_merged_expanded_v1.json"))
+    for c in cases["en"]:
+        assert en.encode(c["prompt"]) == c["ids"], c["prompt"]
+    for c in cases["mtl"]:
+        assert mtl.encode(c["prompt"]) == c["ids"], c["prompt"]
+
+
 def test_sampling_params_validation():
     from chatterbox_vllm2_amd.llm import SamplingParams
     sp = SamplingParams(temperature=0.8, stop_token_ids=[9062], max_tokens=1000, top_p=0.8, repetition_penalty=2.0)
