@@ -109,8 +109,15 @@ __device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
     return c.u;
 }
 
+#ifdef T3_GEMM_CLK      // diagnostic build only (tools/gemm_clk.hip): per-workgroup phase stamps, 100 MHz ticks
+__device__ unsigned long long g_gemm_clk[8][2048][5];
+#define T3_GSTAMP(i) do { if (threadIdx.x == 0) g_gemm_clk[(EPI * 2 + (NW == 16)) & 7][(blockIdx.y * gridDim.x + blockIdx.x) & 2047][i] = wall_clock64(); } while (0)
+#else
+#define T3_GSTAMP(i)
+#endif
 template <int MT, int NT, int EPI, int PD, int NW, bool NORM>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
+    T3_GSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) float red[];   // [NW waves][MT*NT][4 regs][64 lanes] | NORM: [4][MT*16] row sums
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -135,6 +142,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         ssq[i] = 0.0f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // every thread finishes MT*NT*256 / (64*NW) outputs; D[row = 4*(lane>>4) + reg][col = lane&15]
+    constexpr int TOTAL = MT * NT * 256, STEP = NW * 64, ITER = (TOTAL + STEP - 1) / STEP;
+    // EPI_RESID: the residual operand of this thread's outputs is requested now, so that its HBM round trip overlaps
+    // the weight stream instead of sitting between the reduction and the store
+    float hres[ITER];
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) {
+            const int idx = threadIdx.x + k * STEP;
+            const int it = idx >> 8, r = (idx >> 6) & 3, l2 = idx & 63;
+            const int m = (blockIdx.y * MT + it / NT) * 16 + 4 * (l2 >> 4) + r, n = (blockIdx.x * NT + it % NT) * 16 + (l2 & 15);
+            hres[k] = (idx < TOTAL && m < a.M && n < a.N) ? bf2f(reinterpret_cast<const uint16_t*>(a.out)[(size_t)m * a.ldo + n]) : 0.0f;
+        }
     }
 
     uint4 wr[PD][NT], xr[PD][MT], lr[PD];
@@ -170,6 +192,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
                         acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(xr[j][i]), as_frag(wr[j][t]), acc[i][t], 0, 0, 0);
+                if (kb == 0) T3_GSTAMP(1);
                 if (kb + PD < kbs) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) wr[j][t] = ld_nt(wp[t] + (kb + PD) * 64);
@@ -181,6 +204,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         }
     }
 
+    T3_GSTAMP(2);
     // cross-wave (= cross-segment) reduction in segment order
     float* rowsum = red + (size_t)NW * MT * NT * 256;
 #pragma unroll
@@ -198,10 +222,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         }
     }
     __syncthreads();
+    T3_GSTAMP(3);
 
-    // every thread finishes MT*NT*256 / (64*NW) outputs; D[row = 4*(lane>>4) + reg][col = lane&15]
-    constexpr int TOTAL = MT * NT * 256, STEP = NW * 64;
-    for (int idx = threadIdx.x; idx < TOTAL; idx += STEP) {
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const int idx = threadIdx.x + k * STEP;
+        if (idx >= TOTAL) continue;
         const int it = idx >> 8, r = (idx >> 6) & 3, l2 = idx & 63;
         const int i = it / NT, t = it % NT;
         const int m = (blockIdx.y * MT + i) * 16 + 4 * (l2 >> 4) + r;
@@ -241,11 +267,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             } else if constexpr (EPI == EPI_BF16) {
                 reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)f2bf(v[0]);
             } else {   // EPI_RESID: h = bf16(h + bf16(y))
-                uint16_t* hp = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
-                *hp = (uint16_t)f2bf(bf2f(*hp) + rbf(v[0]));
+                reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)f2bf(hres[k] + rbf(v[0]));
             }
         }
     }
+    T3_GSTAMP(4);
 }
 
 int choose_mt(int M, int ntiles_x, int nw, bool norm) {
@@ -270,7 +296,13 @@ int choose_mt(int M, int ntiles_x, int nw, bool norm) {
 template <int MT, int NT, int EPI, int NW, bool NORM>
 static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     // ring depth, bounded by the register file: 4-wave workgroups may use ~200 VGPRs, 16-wave ones 128
-    constexpr int PD = NW == 16 ? (MT <= 2 ? 4 : 2) : (NORM ? (MT * NT <= 2 ? 8 : 4) : ((MT + NT) <= 6 ? 8 : 4));
+#ifndef T3_PD16
+#define T3_PD16 4
+#endif
+#ifndef T3_PDN4
+#define T3_PDN4 4
+#endif
+    constexpr int PD = NW == 16 ? (MT <= 2 ? T3_PD16 : 2) : (NORM ? (MT * NT <= 2 ? 8 : T3_PDN4) : ((MT + NT) <= 6 ? 8 : 4));
     const int ntiles = (a.N + 15) / 16;           // EPI_SILU: N = F -> one workgroup per output tile (2 packed tiles)
     const int gx = (EPI == EPI_SILU) ? ntiles : (ntiles + NT - 1) / NT;
     const int gy = ((a.M + 15) / 16 + MT - 1) / MT;

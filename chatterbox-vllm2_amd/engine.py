@@ -17,7 +17,7 @@ from . import constants as C
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libt3engine.so")
+LIB_PATH = os.environ.get("T3_ENGINE_LIB") or os.path.join(CSRC, "libt3engine.so")     # override: diagnostic builds only
 
 T3_OK, T3_E_INVALID, T3_E_DEVICE, T3_E_NOMEM, T3_E_STATE, T3_E_NOTFOUND = 0, -1, -2, -3, -4, -5
 

@@ -56,6 +56,36 @@ def find_tokenizer_file(kind: str, model_dir: Optional[str] = None, explicit: Op
     return None
 
 
+# text clean-up the reference applies before "[START]" + text + "[STOP]" (text_utils.py:23-58, tts.py:435)
+_PUNC_MAP = (("...", ", "), ("\u2026", ", "), (":", ","), (" - ", ", "), (";", ", "), ("\u2014", "-"), ("\u2013", "-"), (" ,", ","),
+             ("\u201c", '"'), ("\u201d", '"'), ("\u2018", "'"), ("\u2019", "'"))
+_SENTENCE_ENDERS = (".", "!", "?", "-", ",", "\u3001", "\uff0c", "\u3002", "\uff1f", "\uff01")
+_EMPTY_TEXT = "You need to add some text for me to talk."
+
+
+def punc_norm(text: str) -> str:
+    """Capitalise the first letter, collapse whitespace, map rare punctuation, make sure the text ends a sentence."""
+    if not text:
+        return _EMPTY_TEXT
+    if text[0].islower():
+        text = text[0].upper() + text[1:]
+    text = " ".join(text.split())
+    for src, dst in _PUNC_MAP:                 # order matters: "..." before ":" etc.
+        text = text.replace(src, dst)
+    text = text.rstrip(" ")
+    return text if text.endswith(_SENTENCE_ENDERS) else text + "."
+
+
+def build_prompt_strings(texts: Sequence[str], language_id: Optional[str] = None, multilingual: bool = False) -> List[str]:
+    """The strings `ChatterboxTTS.generate_with_conds` hands to `LLM.generate` (tts.py:435-441)."""
+    prompts = ["[START]" + punc_norm(t) + "[STOP]" for t in texts]
+    if multilingual:
+        if not language_id:
+            raise ValueError("language_id is required for the multilingual model")
+        prompts = [f"<{language_id.lower()}>{p}" for p in prompts]
+    return prompts
+
+
 def _korean_normalize(text: str) -> str:
     """Hangul syllables -> conjoining jamo (initial 0x1100+, medial 0x1161+, final 0x11A7+), then strip."""
     out = []

@@ -131,6 +131,12 @@ def g7b_tokenizer_cases():
     for lang, t in mtl_texts:
         prompt = (f"<{lang}>" if lang else "") + "[START]" + t + "[STOP]"    # tts.py:441
         out["mtl"].append({"prompt": prompt, "ids": [int(i) for i in mtl.encode(prompt)]})
+    # text clean-up of tts.py:435 (text_utils.punc_norm, imported)
+    tu = importlib.import_module("chatterbox_vllm.text_utils")
+    raw = ["", " ", "hello world", "Already Capitalised.", "wait... what", "ellipsis… char", "colon: here; semi", "a - b — c – d", "space , comma",
+           "“curly” ‘quotes’", "  many   spaces\tand\nlines  ", "ends with dash-", "ends with comma,", "question?", "日本語のテキスト。", "中文，", "trailing space ",
+           "éclair au chocolat", "1 2 3", "x"]
+    out["punc_norm"] = [{"text": t, "out": tu.punc_norm(t)} for t in raw]
     json.dump(out, open(os.path.join(HERE, "tokenizer_cases.json"), "w"), indent=1, ensure_ascii=False)
     print("G7b tokenizer cases:", len(out["en"]), "en,", len(out["mtl"]), "mtl")
 

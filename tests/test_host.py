@@ -58,6 +58,11 @@ def test_tokenizer_matches_reference_classes():
         assert 255 not in c["ids"]                                            # lower-cased "[start]" is spelled out in pieces
     second = next(c for c in cases["mtl"] if "a > b" in c["prompt"])
     assert len(second["ids"]) == 8                                            # text.split('>')[1]: everything after the 2nd '>' is dropped
+    from chatterbox_vllm2_amd.prompt import build_prompt_strings, punc_norm
+    for c in cases["punc_norm"]:                                              # outputs of the reference's text_utils.punc_norm
+        assert punc_norm(c["text"]) == c["out"], repr(c["text"])
+    assert build_prompt_strings(["hi there"], "ES", multilingual=True) == ["<es>[START]Hi there.[STOP]"]      # tts.py:435-441
+    assert build_prompt_strings(["hi there"]) == ["[START]Hi there.[STOP]"]
     ref = "/root/reference/src/chatterbox_vllm/models/t3"
     if not os.path.exists(ref):
         pytest.skip("reference vocabulary files not present on this machine")

@@ -1,0 +1,63 @@
+// Diagnostic: in-kernel phase timeline of the decode GEMMs in their real launch order (qkv -> o -> gate/up -> down over 30
+// layers of distinct weights, back to back on one stream).  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+// -fhip-fp32-correctly-rounded-divide-sqrt -DT3_GEMM_CLK tools/gemm_clk.hip -o tools/gemm_clk
+#include "../chatterbox-vllm2_amd/csrc/t3_kernels.hip"
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+using namespace t3;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 64, NL = 30;
+    std::vector<uint16_t> rnd(1 << 20);
+    uint32_t st = 12345;
+    for (auto& v : rnd) { st = st * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((st >> 9) & 0x3ff)) ^ ((st >> 3) & 0x8000); }   // small-magnitude bf16
+    auto dev_fill = [&](uint16_t** p, size_t n) { if (hipMalloc((void**)p, n * 2) != hipSuccess) return false; for (size_t o = 0; o < n; o += rnd.size()) (void)hipMemcpy(*p + o, rnd.data(), std::min(rnd.size(), n - o) * 2, hipMemcpyHostToDevice); return true; };
+    std::vector<uint16_t*> wq(NL), wo(NL), wg(NL), wd(NL);
+    for (int l = 0; l < NL; ++l) if (!dev_fill(&wq[l], (size_t)QKV * D) || !dev_fill(&wo[l], (size_t)D * D) || !dev_fill(&wg[l], (size_t)2 * F * D) || !dev_fill(&wd[l], (size_t)D * F)) return 1;
+    uint16_t *h, *qkv, *att, *act, *ln;
+    if (!dev_fill(&h, (size_t)M * D) || !dev_fill(&qkv, (size_t)M * QKV) || !dev_fill(&att, (size_t)M * D) || !dev_fill(&act, (size_t)M * F) || !dev_fill(&ln, D)) return 1;
+    hipStream_t s; CK(hipStreamCreate(&s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto chain = [&]() {
+        for (int l = 0; l < NL; ++l) {
+            { GemmArgs a{h, (const uint4*)wq[l], M, D, QKV, qkv, QKV, 4, ln, nullptr}; if (launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s) != hipSuccess) return false; }
+            { GemmArgs a{att, (const uint4*)wo[l], M, D, D, h, D, 16, nullptr, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
+            { GemmArgs a{h, (const uint4*)wg[l], M, D, F, act, F, 4, ln, nullptr}; if (launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s) != hipSuccess) return false; }
+            { GemmArgs a{act, (const uint4*)wd[l], M, F, D, h, D, 16, nullptr, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
+        }
+        return true;
+    };
+    for (int w = 0; w < 3; ++w) if (!chain()) return 1;
+    CK(hipStreamSynchronize(s));
+    CK(hipEventRecord(e0, s));
+    for (int w = 0; w < 5; ++w) if (!chain()) return 1;
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("M=%d: %d launches, %.2f us per launch, %.1f us per layer (4 GEMMs, eager launches)\n", M, 5 * NL * 4, ms * 1e3 / (5 * NL * 4), ms * 1e3 / (5 * NL));
+    static unsigned long long clk[8][2048][5];
+    CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_gemm_clk), sizeof(clk)));
+    // the LAST launch of each class left its stamps: class = EPI*2 + (NW==16).  o and down share class 5 -> down (the later one) survives.
+    struct { int cls, wgs; const char* name; } K[] = {{EPI_BF16 * 2, (QKV / 16) * ((M + 15) / 16 / choose_mt(M, QKV / 16, 4, true)), "qkv (NORM, 4 waves)"},
+                                                        {EPI_SILU * 2, (F / 16) * ((M + 15) / 16 / choose_mt(M, F / 16, 4, true)), "gate/up (NORM, SiLU)"},
+                                                        {EPI_RESID * 2 + 1, (D / 16) * ((M + 15) / 16 / choose_mt(M, D / 16, 16, false)), "down (16 waves, +resid)"}};
+    for (auto& k : K) {
+        const int n = std::min(k.wgs, 2048);
+        unsigned long long t0min = ~0ull, t4max = 0;
+        for (int i = 0; i < n; ++i) { t0min = std::min(t0min, clk[k.cls][i][0]); t4max = std::max(t4max, clk[k.cls][i][4]); }
+        auto stat = [&](auto f, const char* what) {
+            std::vector<double> v; for (int i = 0; i < n; ++i) v.push_back(f(clk[k.cls][i]) / 100.0);
+            std::sort(v.begin(), v.end());
+            printf("    %-34s min %6.2f  median %6.2f  p90 %6.2f  max %6.2f us\n", what, v[0], v[n / 2], v[n * 9 / 10], v[n - 1]);
+        };
+        printf("%s: %d workgroups, first entry -> last exit %.2f us\n", k.name, n, (t4max - t0min) / 100.0);
+        stat([&](unsigned long long* c) { return (double)(c[0] - t0min); }, "entry after first workgroup");
+        stat([&](unsigned long long* c) { return (double)(c[1] - c[0]); }, "entry -> first tile consumed");
+        stat([&](unsigned long long* c) { return (double)(c[2] - c[1]); }, "rest of the K loop");
+        stat([&](unsigned long long* c) { return (double)(c[3] - c[2]); }, "LDS write + barrier");
+        stat([&](unsigned long long* c) { return (double)(c[4] - c[3]); }, "fold + epilogue + store");
+        stat([&](unsigned long long* c) { return (double)(c[4] - c[0]); }, "workgroup lifetime");
+    }
+    return 0;
+}
