@@ -133,6 +133,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         m = m < a.M ? m : a.M - 1;                 // padded rows re-read the last row; their outputs are dropped
         if (a.row_index) m = a.row_index[m];
         xp[i] = reinterpret_cast<const uint4*>(a.X + (size_t)m * a.K + kb0 * 32 + q * 8);
+#ifdef T3_GEMM_XDUMMY      // timing diagnostic only (wrong results): every wave reads the same 1 KiB of activations
+        xp[i] = reinterpret_cast<const uint4*>(a.X + q * 8 + c * 32);
+#endif
     }
     const uint4* lnp = NORM ? reinterpret_cast<const uint4*>(a.ln_w + kb0 * 32 + q * 8) : nullptr;
     f32x4 acc[MT][NT];
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         const int i = it / NT, t = it % NT;
         const int m = (blockIdx.y * MT + i) * 16 + 4 * (l2 >> 4) + r;
         if (m >= a.M) continue;
-        if (EPI == EPI_SILU && t != 0) continue;
+        if (EPI == EPI_SILU && (t & 1)) continue;                 // packed tiles come in (gate, up) pairs
         float v[EPI == EPI_SILU ? 2 : 1];
 #pragma unroll
         for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u) {
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u) v[u] = v[u] * rstd;
         }
         if constexpr (EPI == EPI_SILU) {
-            const int n = blockIdx.x * 16 + (l2 & 15);      // tile pair index == output tile index
+            const int n = (blockIdx.x * (NT / 2) + (t >> 1)) * 16 + (l2 & 15);      // tile pair index == output tile index
             if (n < a.N)
                 reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)silu_mul_bf(f2bf(v[0]), f2bf(v[1]));
         } else {
@@ -304,7 +307,7 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
 #endif
     constexpr int PD = NW == 16 ? (MT <= 2 ? T3_PD16 : 2) : (NORM ? (MT * NT <= 2 ? 8 : T3_PDN4) : ((MT + NT) <= 6 ? 8 : 4));
     const int ntiles = (a.N + 15) / 16;           // EPI_SILU: N = F -> one workgroup per output tile (2 packed tiles)
-    const int gx = (EPI == EPI_SILU) ? ntiles : (ntiles + NT - 1) / NT;
+    const int gx = (EPI == EPI_SILU) ? (ntiles + NT / 2 - 1) / (NT / 2) : (ntiles + NT - 1) / NT;
     const int gy = ((a.M + 15) / 16 + MT - 1) / MT;
     const size_t lds = ((size_t)NW * MT * NT * 256 + (NORM ? 4 * MT * 16 : 0)) * sizeof(float);
     auto kern = gemm_kernel<MT, NT, EPI, PD, NW, NORM>;
@@ -323,36 +326,55 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
     const bool norm = a.ln_w != nullptr;
     if (a.K % (32 * nw) != 0 || (norm && (a.K != D || nw != 4))) return hipErrorInvalidValue;
     if (nw == 16 && mt > 4) mt = 4;               // LDS: 16 waves x MT x 1 KiB x 4
-#define T3_CASE(E, NT, NWV, NRM)                                             \
+    // n-tiles per workgroup (NORM forms).  Every workgroup re-reads its rows of the activation operand, so at 64 rows the
+    // activations cost as much L2 -> CU traffic as the weights (in-kernel stamps, tools/gemm_clk.hip: the wait for the first
+    // operand tile was 4.2 us against 2.1 us with that traffic removed).  More n-tiles per workgroup divide it, as long as the
+    // grid stays wide enough: measured at 64 rows, qkv 768 -> 192 workgroups -0.95 us, gate/up 512 -> 256 -0.85 us; the
+    // 16-wave form loses (its reduction grows), the gathered head form keeps one tile (its last tile is partial).
+    int nt = epi == EPI_SILU ? 2 : 1;
+    if (norm && !a.row_index && epi != EPI_F32) {
+        static int force = -1;
+        if (force < 0) { const char* e = getenv("T3_GEMM_NT"); force = e ? atoi(e) : 0; }
+        const int ntiles = (a.N + 15) / 16 * (epi == EPI_SILU ? 2 : 1);      // packed weight tiles
+        const int groups = ((a.M + 15) / 16 + mt - 1) / mt;
+        const int want = epi == EPI_SILU ? 256 : 192;
+        for (int c = 4; c > nt; c >>= 1)
+            if (ntiles % c == 0 && (long)(ntiles / c) * groups >= want) { nt = c; break; }
+        if (force == 1 || force == 2 || force == 4) nt = epi == EPI_SILU ? (force < 2 ? 2 : force) : force;
+        if (ntiles % nt) nt = epi == EPI_SILU ? 2 : 1;
+    }
+#define T3_MT(E, NT, NWV, NRM)                                               \
     switch (mt) {                                                            \
         case 1: return launch_gemm_t<1, NT, E, NWV, NRM>(a, s);              \
         case 2: return launch_gemm_t<2, NT, E, NWV, NRM>(a, s);              \
-        case 4: return launch_gemm_t<4, NT, E, NWV, NRM>(a, s);              \
-        default: return launch_gemm_t<(NWV == 16 ? 4 : 8 / NT), NT, E, NWV, NRM>(a, s); \
+        case 4: return launch_gemm_t<(NT == 4 ? 2 : 4), NT, E, NWV, NRM>(a, s);              \
+        default: return launch_gemm_t<(NWV == 16 ? 4 : (NT == 4 ? 2 : 8 / NT)), NT, E, NWV, NRM>(a, s); \
     }
     if (nw == 16) {
         if (norm) return hipErrorInvalidValue;
         switch (epi) {
-            case EPI_F32: T3_CASE(EPI_F32, 1, 16, false)
-            case EPI_RESID: T3_CASE(EPI_RESID, 1, 16, false)
+            case EPI_F32: T3_MT(EPI_F32, 1, 16, false)
+            case EPI_RESID: T3_MT(EPI_RESID, 1, 16, false)
             default: return hipErrorInvalidValue;
         }
     }
     if (norm) {
         switch (epi) {
-            case EPI_F32: T3_CASE(EPI_F32, 1, 4, true)
-            case EPI_BF16: T3_CASE(EPI_BF16, 1, 4, true)
-            case EPI_SILU: T3_CASE(EPI_SILU, 2, 4, true)
+            case EPI_F32: T3_MT(EPI_F32, 1, 4, true)
+            case EPI_BF16:
+                if (nt == 4) { T3_MT(EPI_BF16, 4, 4, true) } else if (nt == 2) { T3_MT(EPI_BF16, 2, 4, true) } else { T3_MT(EPI_BF16, 1, 4, true) }
+            case EPI_SILU:
+                if (nt == 4) { T3_MT(EPI_SILU, 4, 4, true) } else { T3_MT(EPI_SILU, 2, 4, true) }
             default: return hipErrorInvalidValue;
         }
     }
     switch (epi) {
-        case EPI_F32: T3_CASE(EPI_F32, 1, 4, false)
-        case EPI_BF16: T3_CASE(EPI_BF16, 1, 4, false)
-        case EPI_RESID: T3_CASE(EPI_RESID, 1, 4, false)
-        case EPI_SILU: T3_CASE(EPI_SILU, 2, 4, false)
+        case EPI_F32: T3_MT(EPI_F32, 1, 4, false)
+        case EPI_BF16: T3_MT(EPI_BF16, 1, 4, false)
+        case EPI_RESID: T3_MT(EPI_RESID, 1, 4, false)
+        case EPI_SILU: T3_MT(EPI_SILU, 2, 4, false)
     }
-#undef T3_CASE
+#undef T3_MT
     return hipErrorInvalidValue;
 }
 
