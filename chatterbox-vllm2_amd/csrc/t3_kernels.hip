@@ -519,8 +519,16 @@ __device__ __forceinline__ void patch16(uint4& v, int j, uint32_t val) {      //
     v.z = w == 2 ? ((v.z & keep) | ins) : v.z; v.w = w == 3 ? ((v.w & keep) | ins) : v.w;
 }
 
+#ifdef T3_ATTN_CLK      // diagnostic build only (tools/attn_clk.py): per-workgroup phase stamps of the LAST launch, 100 MHz ticks
+__device__ unsigned long long g_attn_clk[4096][6];
+extern "C" int t3_debug_attn_clk(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_clk), sizeof(g_attn_clk)); }
+#define T3_ASTAMP(i) do { if (threadIdx.x == 0) g_attn_clk[(blockIdx.y * gridDim.x + blockIdx.x) & 4095][i] = wall_clock64(); } while (0)
+#else
+#define T3_ASTAMP(i)
+#endif
 template <int NW, bool NT, bool FUSE>
-__global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(AttnArgs a) {
+    T3_ASTAMP(0);
     extern __shared__ __attribute__((aligned(16))) float part[];   // [max_chunks] m | [max_chunks] l | [max_chunks][64] o | per wave: 64 scores, 64 bf16 p
     float* pm = part; float* pl = part + a.max_chunks; float* po = part + 2 * a.max_chunks;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -585,6 +593,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
         qfrag[0] = *reinterpret_cast<const uint4*>(qsrc); qfrag[1] = *reinterpret_cast<const uint4*>(qsrc + 32);
     }
 
+    T3_ASTAMP(1);                                   // prologue (q / RoPE / newest KV write) done
     for (int c = wave; c < nc; c += NW) {
         if (c != wave) load_tiles(c);
         if (FUSE && c == nc - 1) {                  // the newest token is patched into the last tile from registers
@@ -659,8 +668,11 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
         }
         if (lane == 0) { pm[c] = m; pl[c] = lsum; }
         asm volatile("" ::: "memory");              // the next chunk reuses sbuf / pbuf
+        if (c == wave) T3_ASTAMP(2);                // wave 0: first chunk done
     }
+    T3_ASTAMP(3);                                   // wave 0: all its chunks done
     __syncthreads();
+    T3_ASTAMP(4);
     if (wave == 0) {
         float M = -INFINITY;
         for (int c = 0; c < nc; ++c) M = fmaxf(M, pm[c]);
@@ -672,6 +684,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
         }
         a.out[(size_t)row * D + h * HD + lane] = (uint16_t)f2bf(o / l);
     }
+    T3_ASTAMP(5);
 }
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
