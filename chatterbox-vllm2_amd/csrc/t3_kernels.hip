@@ -674,10 +674,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
     __syncthreads();
     T3_ASTAMP(4);
     if (wave == 0) {
+        // fold in ascending chunk order (contract); four chunks' LDS reads are issued together, the fma chain stays sequential
         float M = -INFINITY;
+#pragma unroll 4
         for (int c = 0; c < nc; ++c) M = fmaxf(M, pm[c]);
         float l = 0.0f, o = 0.0f;
-        for (int c = 0; c < nc; ++c) {
+        int c = 0;
+        for (; c + 4 <= nc; c += 4) {
+            float mc[4], lc[4], oc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { mc[u] = pm[c + u]; lc[u] = pl[c + u]; oc[u] = po[(c + u) * 64 + lane]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float w = t3_expf(mc[u] - M);
+                l = __builtin_fmaf(w, lc[u], l);
+                o = __builtin_fmaf(w, oc[u], o);
+            }
+        }
+        for (; c < nc; ++c) {
             const float w = t3_expf(pm[c] - M);
             l = __builtin_fmaf(w, pl[c], l);
             o = __builtin_fmaf(w, po[c * 64 + lane], o);
