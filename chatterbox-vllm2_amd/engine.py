@@ -63,6 +63,8 @@ ABI_SYMBOLS = [
     "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_release_request",
     "t3_clean_tokens", "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_kernel_ms",
     "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_sample", "t3k_expf",
+    "t3_cond_create", "t3_cond_destroy", "t3_cond_last_error", "t3_cond_load_tensor", "t3_cond_encode", "t3_cond_emotion_row",
+    "t3k_ce_layernorm", "t3k_ce_linear", "t3k_ce_attention",
 ]
 
 KERNEL_CLASSES = ["gemm_qkv", "gemm_o", "gemm_gateup", "gemm_down", "gemm_head", "attention", "rmsnorm",
@@ -114,8 +116,17 @@ def load_library():
     L.t3k_rope_attention.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.t3k_sample.argtypes = [vp, i32, vp, ct.POINTER(T3Sampling), ct.c_float, ct.c_uint32, vp, vp]
     L.t3k_expf.argtypes = [vp, vp, i32]
+    L.t3_cond_create.argtypes = [i32, ct.POINTER(vp)]
+    L.t3_cond_destroy.argtypes = [vp]
+    L.t3_cond_last_error.restype = ct.c_char_p; L.t3_cond_last_error.argtypes = [vp]
+    L.t3_cond_load_tensor.argtypes = [vp, ct.c_char_p, vp, i64]
+    L.t3_cond_encode.argtypes = [vp, vp, vp, i32, ct.c_float, vp]
+    L.t3_cond_emotion_row.argtypes = [vp, ct.c_float, vp]
+    L.t3k_ce_layernorm.argtypes = [vp, vp, vp, vp, i32]
+    L.t3k_ce_linear.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32]
+    L.t3k_ce_attention.argtypes = [vp, vp, vp, vp, i32, i32]
     for s in ABI_SYMBOLS:
-        if s != "t3_last_error":
+        if s not in ("t3_last_error", "t3_cond_last_error"):
             getattr(L, s).restype = ct.c_int
     _lib = L
     return L
@@ -324,3 +335,33 @@ def k_expf(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty_like(x)
     _chk_k(load_library().t3k_expf(x.data_ptr(), y.data_ptr(), x.numel()), "t3k_expf")
     return y
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    assert t.device.type == "cpu"
+    return t.detach().to(torch.float32).contiguous()
+
+
+def k_ce_layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    x, w, b = _f32(x), _f32(w), _f32(b)
+    y = torch.empty_like(x)
+    _chk_k(load_library().t3k_ce_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), x.shape[0]), "t3k_ce_layernorm")
+    return y
+
+
+def k_ce_linear(x: torch.Tensor, W: torch.Tensor, bias=None, resid=None) -> torch.Tensor:
+    x, W = _f32(x), _f32(W)
+    bias = _f32(bias) if bias is not None else None
+    resid = _f32(resid) if resid is not None else None
+    out = torch.empty(x.shape[0], W.shape[0], dtype=torch.float32)
+    _chk_k(load_library().t3k_ce_linear(x.data_ptr(), W.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        resid.data_ptr() if resid is not None else None, out.data_ptr(),
+                                        x.shape[0], x.shape[1], W.shape[0]), "t3k_ce_linear")
+    return out
+
+
+def k_ce_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    q, k, v = _f32(q), _f32(k), _f32(v)
+    out = torch.empty_like(q)
+    _chk_k(load_library().t3k_ce_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.shape[0], k.shape[0]), "t3k_ce_attention")
+    return out

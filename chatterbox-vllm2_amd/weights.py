@@ -51,6 +51,42 @@ def synthetic_cond_emb(seed: int = 1) -> torch.Tensor:
     return torch.randn(C.CONDITIONING_SIZE, C.HIDDEN, generator=g, dtype=torch.float32) * 0.02
 
 
+COND_ENC_PARAMS = (                      # checkpoint name under "cond_enc." -> shape   (cond_enc.py:62-78, perceiver.py:137-148, 190-201)
+    ("spkr_enc.weight", (C.HIDDEN, 256)), ("spkr_enc.bias", (C.HIDDEN,)), ("emotion_adv_fc.weight", (C.HIDDEN, 1)),
+    ("perceiver.pre_attention_query", (1, 32, C.HIDDEN)),
+    ("perceiver.attn.norm.weight", (C.HIDDEN,)), ("perceiver.attn.norm.bias", (C.HIDDEN,)),
+    ("perceiver.attn.to_q.weight", (C.HIDDEN, C.HIDDEN)), ("perceiver.attn.to_q.bias", (C.HIDDEN,)),
+    ("perceiver.attn.to_k.weight", (C.HIDDEN, C.HIDDEN)), ("perceiver.attn.to_k.bias", (C.HIDDEN,)),
+    ("perceiver.attn.to_v.weight", (C.HIDDEN, C.HIDDEN)), ("perceiver.attn.to_v.bias", (C.HIDDEN,)),
+    ("perceiver.attn.proj_out.weight", (C.HIDDEN, C.HIDDEN)), ("perceiver.attn.proj_out.bias", (C.HIDDEN,)),
+)
+
+
+def synthetic_cond_enc_tensors(seed: int = 4321) -> Iterator[Tuple[str, torch.Tensor]]:
+    """Seeded fp32 parameters of the conditioning encoder (4 497 408 values), checkpoint names and shapes of the reference's
+    T3CondEnc.  Magnitudes chosen so that every stage matters: O(1/sqrt(fan_in)) matrices, LayerNorm weight near 1."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    for name, shape in COND_ENC_PARAMS:
+        if name.endswith("norm.weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith(".bias"):
+            t = 0.05 * torch.randn(shape, generator=g)
+        elif name.endswith("pre_attention_query"):
+            t = (torch.rand(shape, generator=g) * 2 - 1) * 0.3
+        else:
+            fan_in = shape[-1]
+            t = torch.randn(shape, generator=g) / (fan_in ** 0.5)
+        yield "cond_enc." + name, t.to(torch.float32).contiguous()
+
+
+def synthetic_cond_inputs(seed: int = 7, n_prompt: int = 150):
+    """(speaker_emb [1,256], cond_prompt_speech_emb [n,1024], emotion_adv) stand-ins for tts.py:277-284."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    spk = torch.randn(1, 256, generator=g) * 0.1
+    prompt = torch.randn(n_prompt, C.HIDDEN, generator=g) * 0.05
+    return spk, prompt, 0.5
+
+
 def iter_safetensors(path: str) -> Iterator[Tuple[str, torch.Tensor]]:
     """Yield (name, bf16 tensor) from a reference checkpoint (t3_cfg.safetensors / t3_mtl23ls_v2.safetensors,
     or the ``model.safetensors`` symlink the reference creates, tts.py:225-229)."""

@@ -150,6 +150,31 @@ int t3_reset_stats(T3Handle h);
 int t3_set_profile(T3Handle h, int32_t on);
 int t3_kernel_ms(T3Handle h, const char* name, double* avg_ms, int64_t* launches);
 
+/* ---- conditioning encoder --------------------------------------------------
+ * Replaces the reference's torch module `T3CondEnc` (models/t3/modules/cond_enc.py:57-123 with modules/perceiver.py:118-215),
+ * as ChatterboxTTS uses it: `self.t3_cond_enc(T3Cond(speaker_emb, cond_prompt_speech_tokens, cond_prompt_speech_emb,
+ * emotion_adv))` (tts.py:279-284) and `self.t3_cond_enc.emotion_adv_fc(exaggeration)` (tts.py:287-298).  fp32, on the device;
+ * a handle of its own because the reference keeps this module outside the vLLM engine.  No CPU fallback.            */
+typedef struct T3CondEncoder* T3CondHandle;
+int t3_cond_create(int32_t device_id, T3CondHandle* out);
+int t3_cond_destroy(T3CondHandle c);
+const char* t3_cond_last_error(T3CondHandle c);          /* c may be NULL after a failed create */
+/* fp32 parameters under their checkpoint names, with or without the "cond_enc." prefix (state_dict of T3CondEnc):
+ * spkr_enc.{weight [1024][256], bias}, emotion_adv_fc.weight [1024][1], perceiver.pre_attention_query [1][32][1024],
+ * perceiver.attn.norm.{weight,bias}, perceiver.attn.{to_q,to_k,to_v,proj_out}.{weight [1024][1024], bias}.
+ * Other names return T3_E_NOTFOUND. */
+int t3_cond_load_tensor(T3CondHandle c, const char* name, const float* data, int64_t numel);
+/* T3CondEnc.forward: speaker_emb [256], cond_prompt_speech_emb [n][1024] (= speech_emb(tokens) + speech_pos_emb(tokens),
+ * tts.py:277; 1 <= n <= 192, the reference uses 150), emotion_adv scalar -> out [34][1024] = [speaker; 32 perceiver rows; emotion]. */
+int t3_cond_encode(T3CondHandle c, const float* speaker_emb, const float* prompt_emb, int32_t n, float emotion_adv, float* out);
+/* emotion_adv_fc(exaggeration) -> out [1024] (the row ChatterboxTTS.update_exaggeration writes into cond_emb[-1]) */
+int t3_cond_emotion_row(T3CondHandle c, float exaggeration, float* out);
+/* kernel-level entry points of the encoder (host buffers), for the parity tests */
+int t3k_ce_layernorm(const float* x /*[rows][1024]*/, const float* w, const float* b, float* y, int32_t rows);
+int t3k_ce_linear(const float* x /*[M][K]*/, const float* W /*[N][K]*/, const float* bias /*nullable*/, const float* resid /*nullable [M][N]*/,
+                  float* out /*[M][N]*/, int32_t M, int32_t K /*multiple of 32*/, int32_t N);
+int t3k_ce_attention(const float* q /*[nq][1024]*/, const float* k /*[nk][1024]*/, const float* v, float* out /*[nq][1024]*/, int32_t nq, int32_t nk);
+
 /* ---- kernel-level entry points (host buffers in, host buffers out; used by the parity tests) ----
  * Each runs exactly the kernel the engine uses, on the current device, and waits for it.      */
 int t3k_gemm(const void* x_bf16 /*[M][K]*/, const void* w_bf16 /*[N][K]*/, int32_t M, int32_t K, int32_t N,

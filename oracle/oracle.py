@@ -85,6 +85,10 @@ def lib():
         L.orc_generate.restype = i32
         L.orc_generate.argtypes = [vp, i32, vp, i32, vp, ct.POINTER(Sampling), f32, i32, vp, vp]
         L.orc_decode_steps_timing.argtypes = [vp, i32, i32, i32]
+        L.orc_ce_layernorm.argtypes = [vp, vp, vp, vp, i32]
+        L.orc_ce_linear.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32]
+        L.orc_ce_attention.restype = i32; L.orc_ce_attention.argtypes = [vp, vp, vp, vp, i32, i32]
+        L.orc_cond_enc.restype = i32; L.orc_cond_enc.argtypes = [vp, vp, vp, i32, f32, vp]
         _lib = L
     return _lib
 
@@ -176,6 +180,52 @@ def sample(logits: torch.Tensor, counts: torch.Tensor, sp: Sampling, step: int) 
 
 
 # ---------------------------------------------------------------- model-level
+CE_ORDER = ("spkr_enc.weight", "spkr_enc.bias", "emotion_adv_fc.weight", "perceiver.pre_attention_query",
+            "perceiver.attn.norm.weight", "perceiver.attn.norm.bias",
+            "perceiver.attn.to_q.weight", "perceiver.attn.to_q.bias", "perceiver.attn.to_k.weight", "perceiver.attn.to_k.bias",
+            "perceiver.attn.to_v.weight", "perceiver.attn.to_v.bias", "perceiver.attn.proj_out.weight", "perceiver.attn.proj_out.bias")
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def ce_layernorm(x, w, b):
+    x = _f32(x); y = torch.empty_like(x)
+    lib().orc_ce_layernorm(_p(x), _p(_f32(w)), _p(_f32(b)), _p(y), x.shape[0])
+    return y
+
+
+def ce_linear(x, W, bias=None, resid=None):
+    x = _f32(x); W = _f32(W)
+    out = torch.empty(x.shape[0], W.shape[0], dtype=torch.float32)
+    bias = _f32(bias) if bias is not None else None; resid = _f32(resid) if resid is not None else None
+    lib().orc_ce_linear(_p(x), _p(W), _p(bias) if bias is not None else None, _p(resid) if resid is not None else None, _p(out),
+                        x.shape[0], x.shape[1], W.shape[0])
+    return out
+
+
+def ce_attention(q, k, v):
+    q, k, v = _f32(q), _f32(k), _f32(v)
+    out = torch.empty_like(q)
+    rc = lib().orc_ce_attention(_p(q), _p(k), _p(v), _p(out), q.shape[0], k.shape[0])
+    if rc:
+        raise ValueError("ce_attention: key count out of range")
+    return out
+
+
+def cond_enc(params: dict, speaker_emb, prompt_emb, emotion: float) -> torch.Tensor:
+    """params: {"cond_enc.<name>": fp32 tensor} -> [34, 1024] fp32 (the reference's T3CondEnc.forward, cond_enc.py:80-123)."""
+    keep = [_f32(params["cond_enc." + n]) for n in CE_ORDER]
+    arr = (ct.c_void_p * len(keep))(*[_p(t) for t in keep])
+    spk = _f32(speaker_emb).reshape(-1); pe = _f32(prompt_emb)
+    out = torch.empty(34, 1024, dtype=torch.float32)
+    rc = lib().orc_cond_enc(arr, _p(spk), _p(pe), pe.shape[0], ct.c_float(emotion), _p(out))
+    if rc:
+        raise ValueError("cond_enc: prompt length out of range")
+    return out
+
+
 class OracleModel:
     def __init__(self, n_layers: int, text_vocab: int, max_pos: int = 1024, n_streams: int = 2):
         self.n_layers, self.text_vocab, self.max_pos, self.n_streams = n_layers, text_vocab, max_pos, n_streams

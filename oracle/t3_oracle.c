@@ -745,3 +745,105 @@ void orc_decode_steps_timing(OrcModel* m, int B, int ctx, int steps) {
     }
     free(h); free(rs); free(rp); free(lg);
 }
+
+/* ====================================================================================================
+ * Conditioning encoder: reference cond_enc.py:57-123 (T3CondEnc.forward) and
+ * perceiver.py:118-215 (AttentionBlock2, Perceiver), fp32 as the reference runs it (tts.py:277-284).
+ *   row 0      = spkr_enc(speaker_emb)                                  cond_enc.py:86-87
+ *   rows 1..32 = Perceiver(cond_prompt_speech_emb): attn(query, h) then attn(pre, pre), ONE AttentionBlock2
+ *                (shared weights): LayerNorm both inputs, q/k/v Linear, 4 heads x 256 softmax(q k^T / 16) v,
+ *                proj_out, + x1                                          perceiver.py:150-167, 203-212
+ *   row 33     = emotion_adv_fc(emotion_adv) (Linear 1 -> 1024, no bias) cond_enc.py:103-106
+ * Pinned against outputs of the reference's own T3CondEnc (tests/golden/cond_enc.npz, make_golden.py g1) within
+ * an fp32 tolerance; the ORDER of every sum below is the contract the HIP kernels repeat bit for bit:
+ *   dot      : acc = 0; k ascending: acc = fma(x[k], w[k], acc); linear = (acc + bias) [+ residual, added last]
+ *   LayerNorm: lane l of 64 adds elements l, l+64, ... (16, ascending), butterfly xor 32..1; mean = sum/1024;
+ *              second pass the same over fma(d, d, acc), d = x - mean; y = fma((x - mean) * rstd, w, b),
+ *              rstd = 1/sqrt(var + 1e-5)
+ *   attention: one (head, query): s_j = dot_256(q, k_j) * 0.0625; m = max; p_j = orc_expf(s_j - m); lane l adds
+ *              p_l, p_{l+64}, p_{l+128} (ascending), butterfly; out_d = (j ascending: acc = fma(p_j, v_jd, acc)) / l
+ * ==================================================================================================== */
+#define CE_HEADS 4
+#define CE_HD 256
+#define CE_Q 32
+#define CE_MAXK 192
+
+void orc_ce_layernorm(const float* x, const float* w, const float* b, float* y, int rows) {
+    static const int offs[6] = {32, 16, 8, 4, 2, 1};
+    for (int r = 0; r < rows; ++r) {
+        const float* xr = x + (size_t)r * T3_D;
+        float v[64];
+        for (int l = 0; l < 64; ++l) { float a = 0.0f; for (int i = 0; i < 16; ++i) a = a + xr[l + 64 * i]; v[l] = a; }
+        bfly_add(v, offs, 6);
+        const float mean = v[0] * (1.0f / 1024.0f);
+        for (int l = 0; l < 64; ++l) { float a = 0.0f; for (int i = 0; i < 16; ++i) { const float d = xr[l + 64 * i] - mean; a = fmaf(d, d, a); } v[l] = a; }
+        bfly_add(v, offs, 6);
+        const float rstd = 1.0f / sqrtf(v[0] * (1.0f / 1024.0f) + 1e-5f);
+        for (int i = 0; i < T3_D; ++i) y[(size_t)r * T3_D + i] = fmaf((xr[i] - mean) * rstd, w[i], b[i]);
+    }
+}
+
+void orc_ce_linear(const float* x, const float* W, const float* bias, const float* resid, float* out, int M, int K, int N) {
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int m = 0; m < M; ++m) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; ++k) acc = fmaf(x[(size_t)m * K + k], W[(size_t)n * K + k], acc);
+            if (bias) acc = acc + bias[n];
+            if (resid) acc = resid[(size_t)m * N + n] + acc;
+            out[(size_t)m * N + n] = acc;
+        }
+}
+
+int orc_ce_attention(const float* q, const float* k, const float* v, float* out, int nq, int nk) {
+    static const int offs[6] = {32, 16, 8, 4, 2, 1};
+    if (nk <= 0 || nk > CE_MAXK) return -1;
+    for (int h = 0; h < CE_HEADS; ++h)
+        for (int i = 0; i < nq; ++i) {
+            float s[CE_MAXK], p[CE_MAXK], lane[64];
+            for (int j = 0; j < nk; ++j) {
+                float acc = 0.0f;
+                for (int d = 0; d < CE_HD; ++d) acc = fmaf(q[(size_t)i * T3_D + h * CE_HD + d], k[(size_t)j * T3_D + h * CE_HD + d], acc);
+                s[j] = acc * 0.0625f;
+            }
+            float m = -INFINITY;
+            for (int j = 0; j < nk; ++j) m = fmaxf(m, s[j]);
+            for (int j = 0; j < nk; ++j) p[j] = orc_expf(s[j] - m);
+            for (int l = 0; l < 64; ++l) { float a = 0.0f; for (int j = l; j < nk; j += 64) a = a + p[j]; lane[l] = a; }
+            bfly_add(lane, offs, 6);
+            const float lsum = lane[0];
+            for (int d = 0; d < CE_HD; ++d) {
+                float acc = 0.0f;
+                for (int j = 0; j < nk; ++j) acc = fmaf(p[j], v[(size_t)j * T3_D + h * CE_HD + d], acc);
+                out[(size_t)i * T3_D + h * CE_HD + d] = acc / lsum;
+            }
+        }
+    return 0;
+}
+
+/* params, in this order: spkr_w[1024][256], spkr_b[1024], emotion_w[1024], query[32][1024], ln_w[1024], ln_b[1024],
+ * wq, bq, wk, bk, wv, bv, wo, bo  (matrices [1024][1024], biases [1024]).  prompt_emb [n][1024]; out [34][1024]. */
+static void ce_block(const float* const* P, const float* x1, int n1, const float* x2, int n2, float* out) {
+    float* a1 = (float*)malloc((size_t)n1 * T3_D * 4), *a2 = (float*)malloc((size_t)n2 * T3_D * 4);
+    float* q = (float*)malloc((size_t)n1 * T3_D * 4), *k = (float*)malloc((size_t)n2 * T3_D * 4), *v = (float*)malloc((size_t)n2 * T3_D * 4);
+    float* at = (float*)malloc((size_t)n1 * T3_D * 4);
+    orc_ce_layernorm(x1, P[4], P[5], a1, n1);
+    orc_ce_layernorm(x2, P[4], P[5], a2, n2);
+    orc_ce_linear(a1, P[6], P[7], NULL, q, n1, T3_D, T3_D);
+    orc_ce_linear(a2, P[8], P[9], NULL, k, n2, T3_D, T3_D);
+    orc_ce_linear(a2, P[10], P[11], NULL, v, n2, T3_D, T3_D);
+    orc_ce_attention(q, k, v, at, n1, n2);
+    orc_ce_linear(at, P[12], P[13], x1, out, n1, T3_D, T3_D);
+    free(a1); free(a2); free(q); free(k); free(v); free(at);
+}
+
+int orc_cond_enc(const float* const* P, const float* spk, const float* prompt_emb, int n, float emotion, float* out) {
+    if (n <= 0 || n > CE_MAXK) return -1;
+    orc_ce_linear(spk, P[0], P[1], NULL, out, 1, 256, T3_D);
+    float* pre = (float*)malloc((size_t)CE_Q * T3_D * 4);
+    ce_block(P, P[3], CE_Q, prompt_emb, n, pre);
+    ce_block(P, pre, CE_Q, pre, CE_Q, out + T3_D);
+    free(pre);
+    for (int i = 0; i < T3_D; ++i) out[(size_t)33 * T3_D + i] = P[2][i] * emotion;
+    return 0;
+}

@@ -73,6 +73,28 @@ def g1_cond_enc():
     print("G1 cond_enc:", out.shape, float(out.abs().mean()))
 
 
+def g1b_cond_enc_synthetic():
+    """f3 pin: the reference's T3CondEnc (imported) with the product's seeded synthetic parameters loaded into it, fp32 CPU,
+    on seeded inputs -> cond_emb [34,1024] for two prompt lengths, plus the exaggeration row of tts.py:287-298."""
+    from chatterbox_vllm2_amd.weights import synthetic_cond_enc_tensors, synthetic_cond_inputs
+    cfg, lpe, ce = import_reference_leaf_modules()
+    hp = cfg.T3Config.multilingual()
+    enc = ce.T3CondEnc(hp).eval()
+    sd = {k[len("cond_enc."):]: v for k, v in synthetic_cond_enc_tensors(4321)}
+    missing, unexpected = enc.load_state_dict(sd, strict=True)
+    out = {}
+    with torch.no_grad():
+        for n in (150, 37):
+            spk, prompt, emo = synthetic_cond_inputs(7, n)
+            y = enc(ce.T3Cond(speaker_emb=spk, cond_prompt_speech_tokens=torch.zeros(1, n, dtype=torch.long),
+                              cond_prompt_speech_emb=prompt, emotion_adv=emo * torch.ones(1, 1)))
+            assert tuple(y.shape) == (34, 1024)
+            out[f"cond_emb_n{n}"] = y.numpy()
+        out["emotion_row_0p9"] = enc.emotion_adv_fc(0.9 * torch.ones(1, 1)).numpy()
+    np.savez_compressed(os.path.join(HERE, "cond_enc_synth.npz"), **out)
+    print("G1b cond_enc (synthetic params):", {k: (v.shape, float(np.abs(v).mean())) for k, v in out.items()})
+
+
 def g3_rope():
     from transformers import LlamaConfig
     from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
@@ -210,8 +232,9 @@ def g8_postfilter():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g7", "g7b", "g6", "g8"]
+    which = sys.argv[1:] or ["g1", "g1b", "g3", "g7", "g7b", "g6", "g8"]
     if "g1" in which: g1_cond_enc()
+    if "g1b" in which: g1b_cond_enc_synthetic()
     if "g3" in which: g3_rope()
     if "g7" in which: g7_tokenizer()
     if "g7b" in which: g7b_tokenizer_cases()

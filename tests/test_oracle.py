@@ -177,3 +177,20 @@ def test_golden_streams_regression(oracle):
     assert np.array_equal(lg[63].numpy().view(np.int32), z["l2_en_greedy_logits_step63"].view(np.int32))
     ids, _ = m.generate(p, cond, oracle.make_sampling(temperature=0.8, top_p=0.8, repetition_penalty=2.0, max_tokens=64, ignore_eos=True), max_model_len=400)
     assert ids == z["l2_en_sampled_ids"].tolist()
+
+
+@pytest.mark.parametrize("n", [150, 37])
+def test_cond_enc_oracle_matches_reference_module(oracle, n):
+    """SURVEY.md 8 f3 pin: the oracle's conditioning encoder against outputs of the reference's own T3CondEnc
+    (imported when tests/golden/cond_enc_synth.npz was made, with the product's seeded parameters loaded into it).
+    Tolerance 2e-5 absolute on values of magnitude ~0.5: fp32 with a different (unspecified) summation order in torch."""
+    from chatterbox_vllm2_amd.weights import synthetic_cond_enc_tensors, synthetic_cond_inputs
+    params = dict(synthetic_cond_enc_tensors(4321))
+    assert sum(v.numel() for v in params.values()) == 4497408        # n_params of the reference module (cond_enc.npz)
+    spk, prompt, emo = synthetic_cond_inputs(7, n)
+    got = oracle.cond_enc(params, spk, prompt, emo).numpy()
+    g = np.load(os.path.join(G, "cond_enc_synth.npz"))
+    ref = g[f"cond_emb_n{n}"]
+    assert got.shape == ref.shape == (34, 1024)
+    assert np.abs(got - ref).max() < 2e-5
+    assert np.array_equal(got[33], params["cond_enc.emotion_adv_fc.weight"].numpy()[:, 0] * np.float32(emo))
