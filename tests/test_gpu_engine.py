@@ -143,6 +143,31 @@ def test_run_ahead_with_stop_tokens(E, oracle, tiny_weights, tiny_oracle, cond, 
     eng.close()
 
 
+def test_decode_across_kv_block_boundaries(E, oracle, tiny_weights, cond):
+    """Physical KV blocks hold 256 tokens: decode steps whose newest position crosses 255 -> 256 and 511 -> 512 (fused RoPE /
+    KV-write / attention path, block-table lookups, last-tile patching) against the oracle, ragged batch, sampled and greedy."""
+    eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=560, max_seqs=4, kv_bytes=1 << 30, enforce_eager=False)
+    eng.load_tensors(tiny_weights); eng.finalize()
+    m = oracle.OracleModel(2, 704, max_pos=560, n_streams=2).load(tiny_weights)
+    reqs = []
+    for i, (n_text, kw) in enumerate([(211, dict(temperature=0.0)), (466, dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=2, uid=1)),
+                                      (30, dict(temperature=0.8, top_p=0.9, repetition_penalty=1.3, seed=2, uid=2))]):
+        prompt = make_prompt(n_text, seed=90 + i)
+        T = len(prompt)
+        n = {0: 24, 1: 24, 2: 260}[i]                 # 246..270, 501..525, 65..325
+        assert T + n < 560
+        kw = dict(max_tokens=n, ignore_eos=True, **kw)
+        reqs.append((i, prompt, kw))
+        eng.add_request(i, prompt, cond, E.make_sampling(**kw))
+    assert len(reqs[0][1]) < 256 < len(reqs[0][1]) + 24 and len(reqs[1][1]) < 512 < len(reqs[1][1]) + 24
+    eng.run_until_done()
+    for i, prompt, kw in reqs:
+        got, _ = eng.get_output(i)
+        want, _ = m.generate(prompt, cond, oracle.make_sampling(**kw), max_model_len=560)
+        assert [t - 2500 for t in got] == want, f"utterance {i}"
+    m.close(); eng.close()
+
+
 def test_chunked_prefill_equals_whole(E, tiny_weights, cond):
     """A row budget smaller than one prompt forces the prompt through several steps; ids must not change."""
     outs = []
