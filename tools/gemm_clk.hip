@@ -9,6 +9,7 @@ using namespace t3;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 64, NL = 30;
+    const int qkv_mt_arg = argc > 2 ? atoi(argv[2]) : 0, gu_mt_arg = argc > 3 ? atoi(argv[3]) : 0;     // 0 = the engine's choice
     std::vector<uint16_t> rnd(1 << 20);
     uint32_t st = 12345;
     for (auto& v : rnd) { st = st * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((st >> 9) & 0x3ff)) ^ ((st >> 3) & 0x8000); }   // small-magnitude bf16
@@ -21,9 +22,9 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto chain = [&]() {
         for (int l = 0; l < NL; ++l) {
-            { GemmArgs a{h, (const uint4*)wq[l], M, D, QKV, qkv, QKV, 4, ln, nullptr}; if (launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s) != hipSuccess) return false; }
+            { GemmArgs a{h, (const uint4*)wq[l], M, D, QKV, qkv, QKV, 4, ln, nullptr}; if (launch_gemm(a, EPI_BF16, qkv_mt_arg ? qkv_mt_arg : choose_mt(M, QKV / 16, 4, true), s) != hipSuccess) return false; }
             { GemmArgs a{att, (const uint4*)wo[l], M, D, D, h, D, 16, nullptr, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
-            { GemmArgs a{h, (const uint4*)wg[l], M, D, F, act, F, 4, ln, nullptr}; if (launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s) != hipSuccess) return false; }
+            { GemmArgs a{h, (const uint4*)wg[l], M, D, F, act, F, 4, ln, nullptr}; if (launch_gemm(a, EPI_SILU, gu_mt_arg ? gu_mt_arg : choose_mt(M, F / 16, 4, true), s) != hipSuccess) return false; }
             { GemmArgs a{act, (const uint4*)wd[l], M, F, D, h, D, 16, nullptr, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
         }
         return true;
