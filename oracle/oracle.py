@@ -67,7 +67,6 @@ def lib():
         vp, i32, f32 = ct.c_void_p, ct.c_int, ct.c_float
         L.orc_expf.restype = f32; L.orc_expf.argtypes = [f32]
         L.orc_gemm_nk.argtypes = [vp, vp, i32, i32, i32, vp, i32]
-        L.orc_rmsnorm.argtypes = [vp, vp, vp, i32]
         L.orc_norm_gemm_nk.argtypes = [vp, vp, vp, i32, i32, vp]
         L.orc_row_rstd.argtypes = [vp, i32, vp]
         L.orc_rope_table.argtypes = [i32, vp, vp]
@@ -131,13 +130,6 @@ def row_rstd(h: torch.Tensor) -> torch.Tensor:
     h = _bf(h); out = torch.empty(h.shape[0], dtype=torch.float32)
     lib().orc_row_rstd(_p(h), h.shape[0], _p(out))
     return out
-
-
-def rmsnorm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    x, w = _bf(x), _bf(w)
-    y = torch.empty_like(x)
-    lib().orc_rmsnorm(_p(x), _p(w), _p(y), x.shape[0])
-    return y
 
 
 def rope_table(max_pos: int):

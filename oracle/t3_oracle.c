@@ -279,33 +279,6 @@ static void bfly_add(float v[64], const int* offs, int n) {
     }
 }
 
-/* ------------------------------------------------------------------ RMSNorm (stand-alone form)
- * NOT on the model path any more (the path folds the norm into the consuming GEMM, orc_norm_gemm_w); kept as the
- * restatement of the stand-alone kernel the C ABI still exports (t3k_rmsnorm).
- * One row of 1024 bf16.  Lane l (0..63) owns elements 8l..8l+7 then 512+8l..512+8l+7,
- * ss_l = sequential x*x adds; butterfly add over xor 32,16,8,4,2,1;
- * rstd = 1/sqrt(ss/1024 + eps) (IEEE sqrt, IEEE divide);
- * y = bf16( bf16(x*rstd) * w )          (the double rounding mirrors vLLM / HF Llama).   */
-void orc_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* y, int rows) {
-    static const int offs[6] = {32, 16, 8, 4, 2, 1};
-    for (int r = 0; r < rows; ++r) {
-        const uint16_t* xr = x + (size_t)r * T3_D; uint16_t* yr = y + (size_t)r * T3_D;
-        float ss[64];
-        for (int l = 0; l < 64; ++l) {
-            float a = 0.0f;
-            for (int e = 0; e < 8; ++e) { float v = bf2f(xr[8 * l + e]); a = fmaf(v, v, a); }
-            for (int e = 0; e < 8; ++e) { float v = bf2f(xr[512 + 8 * l + e]); a = fmaf(v, v, a); }
-            ss[l] = a;
-        }
-        bfly_add(ss, offs, 6);
-        const float rstd = 1.0f / sqrtf(ss[0] * (1.0f / 1024.0f) + T3_EPS);
-        for (int i = 0; i < T3_D; ++i) {
-            float n = rbf(bf2f(xr[i]) * rstd);
-            yr[i] = f2bf(n * bf2f(w[i]));
-        }
-    }
-}
-
 /* ------------------------------------------------------------------ RoPE table (llama3 scaling)
  * config.json:21-28.  inv_freq in double, angle = pos * inv_freq in double, cos/sin in
  * double -> fp32 -> bf16 (the cache is held in the model dtype as vLLM/HF do).
