@@ -56,9 +56,9 @@ struct Request {
     bool zombie = false;
 };
 
-enum KClass { K_QKV, K_O, K_GU, K_DOWN, K_HEAD, K_ATTN, K_NORM, K_ROPE, K_EMBED, K_SAMPLE, K_COUNT };
+enum KClass { K_QKV, K_O, K_GU, K_DOWN, K_HEAD, K_ATTN, K_ROPE, K_EMBED, K_SAMPLE, K_COUNT };
 static const char* kclass_names[K_COUNT] = {"gemm_qkv", "gemm_o", "gemm_gateup", "gemm_down", "gemm_head",
-                                            "attention", "rmsnorm", "rope_kv", "embed", "sampler"};
+                                            "attention", "rope_kv", "embed", "sampler"};
 
 }  // namespace
 

@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     "t3k_ce_layernorm", "t3k_ce_linear", "t3k_ce_attention",
 ]
 
-KERNEL_CLASSES = ["gemm_qkv", "gemm_o", "gemm_gateup", "gemm_down", "gemm_head", "attention", "rmsnorm",
+KERNEL_CLASSES = ["gemm_qkv", "gemm_o", "gemm_gateup", "gemm_down", "gemm_head", "attention",
                   "rope_kv", "embed", "sampler"]
 
 

@@ -146,7 +146,7 @@ int t3_stats(T3Handle h, T3Stats* out);
 int t3_reset_stats(T3Handle h);
 /* Average duration (ms) per launch of each kernel class over decode-only steps since the last reset,
  * measured with HIP events on the engine's stream when profiling is on (t3_set_profile).
- * names: "gemm_qkv","gemm_o","gemm_gateup","gemm_down","gemm_head","attention","rmsnorm" (unused: folded),"rope_kv","embed","sampler". */
+ * names: "gemm_qkv","gemm_o","gemm_gateup","gemm_down","gemm_head","attention","rope_kv","embed","sampler". */
 int t3_set_profile(T3Handle h, int32_t on);
 int t3_kernel_ms(T3Handle h, const char* name, double* avg_ms, int64_t* launches);
 
