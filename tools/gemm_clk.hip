@@ -6,6 +6,20 @@
 #include <cstdio>
 #include <vector>
 using namespace t3;
+// Experiment: a helper kernel on a SECOND stream pulls the next GEMM's weights into the XCD-local L2 slices while the current GEMM
+// runs (unit u = what consumer workgroup x = u streams, consumed on XCD u % 8).  argv[4] = 1 enables it.
+__global__ __launch_bounds__(256) void l2_warm_kernel(const uint4* base, int units, int unit_kib, uint32_t* sink) {
+    const int p = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+    const int wp = (gridDim.x >> 3) * 4, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lines = (units >> 3) * unit_kib;
+    uint32_t x = 0;
+    for (int l = (blockIdx.x >> 3) * 4 + wave; l < lines; l += wp) {
+        const int unit = (l / unit_kib) * 8 + p, off = l % unit_kib;
+        const uint4 v = base[((size_t)unit * unit_kib + off) * 64 + lane];
+        x ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (x == 0x9e3779b9u && lane == 77) *sink = x;
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 64, NL = 30;
@@ -19,12 +33,27 @@ int main(int argc, char** argv) {
     uint16_t *h, *qkv, *att, *act, *ln;
     if (!dev_fill(&h, (size_t)M * D) || !dev_fill(&qkv, (size_t)M * QKV) || !dev_fill(&att, (size_t)M * D) || !dev_fill(&act, (size_t)M * F) || !dev_fill(&ln, D)) return 1;
     hipStream_t s; CK(hipStreamCreate(&s));
+    const int warm = argc > 4 ? atoi(argv[4]) : 0;
+    hipStream_t s2; CK(hipStreamCreate(&s2));
+    hipEvent_t ev[8]; for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    uint32_t* sink; CK(hipMalloc((void**)&sink, 4));
+    int evi = 0;
+    auto warm_next = [&](const uint16_t* w, int units, int unit_kib) {      // runs beside the GEMM launched right after this call
+        if (!warm) return;
+        hipEvent_t e = ev[evi++ & 7];
+        (void)hipEventRecord(e, s); (void)hipStreamWaitEvent(s2, e, 0);
+        hipLaunchKernelGGL(l2_warm_kernel, dim3(warm), dim3(256), 0, s2, (const uint4*)w, units, unit_kib, sink);
+    };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto chain = [&]() {
         for (int l = 0; l < NL; ++l) {
+            warm_next(wo[l], 64, 32);                          // beside qkv: o_proj weights (64 units of 32 KiB)
             { GemmArgs a{h, (const uint4*)wq[l], M, D, QKV, qkv, QKV, 4, ln, nullptr}; if (launch_gemm(a, EPI_BF16, qkv_mt_arg ? qkv_mt_arg : choose_mt(M, QKV / 16, 4, true), s) != hipSuccess) return false; }
+            warm_next(wg[l], 128, 128);                        // beside o_proj: gate/up weights (128 units of 4 packed tiles)
             { GemmArgs a{att, (const uint4*)wo[l], M, D, D, h, D, 16, nullptr, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
+            warm_next(wd[l], 64, 128);                         // beside gate/up: down_proj weights (64 units of 128 KiB)
             { GemmArgs a{h, (const uint4*)wg[l], M, D, F, act, F, 4, ln, nullptr}; if (launch_gemm(a, EPI_SILU, gu_mt_arg ? gu_mt_arg : choose_mt(M, F / 16, 4, true), s) != hipSuccess) return false; }
+            warm_next(wq[(l + 1) % NL], 48, 128);              // beside down_proj: the next layer's qkv weights (48 units of 4 tiles)
             { GemmArgs a{act, (const uint4*)wd[l], M, F, D, h, D, 16, nullptr, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
         }
         return true;
