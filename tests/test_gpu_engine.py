@@ -168,6 +168,25 @@ def test_decode_across_kv_block_boundaries(E, oracle, tiny_weights, cond):
     m.close(); eng.close()
 
 
+def test_long_prompt_many_blocks(E, oracle, tiny_weights, cond):
+    """A 1100-token prompt (1065 text ids: text positions up to 1064, five 256-token KV blocks per stream) prefilled in
+    chunks of at most 512 rows, then decoded: ids against the oracle."""
+    eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=1200, max_seqs=2, kv_bytes=1 << 30, max_batched_rows=1024, enforce_eager=False)
+    eng.load_tensors(tiny_weights); eng.finalize()
+    prompt = make_prompt(1065, seed=5)
+    assert len(prompt) == 1100
+    kw = dict(temperature=0.0, max_tokens=6, ignore_eos=True)
+    eng.add_request(0, prompt, cond, E.make_sampling(**kw))
+    eng.run_until_done()
+    got, _ = eng.get_output(0)
+    m = oracle.OracleModel(2, 704, max_pos=1200, n_streams=2).load(tiny_weights)
+    want, _ = m.generate(prompt, cond, oracle.make_sampling(**kw), max_model_len=1200)
+    assert [t - 2500 for t in got] == want
+    with pytest.raises(ValueError):                    # longer than max_model_len (and than the 2050 learned text positions)
+        eng.add_request(1, make_prompt(2052, seed=6), cond, E.make_sampling(max_tokens=1))
+    m.close(); eng.close()
+
+
 def test_chunked_prefill_equals_whole(E, tiny_weights, cond):
     """A row budget smaller than one prompt forces the prompt through several steps; ids must not change."""
     outs = []
