@@ -301,7 +301,7 @@ extern "C" int t3_load_tensor(T3Handle e, const char* name, const void* data, in
     if (n == "speech_head.weight") {
         if (!need(V, D)) return e->fail(T3_E_INVALID, "bad shape for speech_head.weight");
         if ((rc = to_host(e, data, bytes, host))) return rc;
-        e->have[5] = true; return upload_packed(e, host.data(), V, D, VPAD, &e->head);
+        e->have[5] = true; return upload_packed(e, host.data(), V, D, HEAD_TILES * 16, &e->head);
     }
     return e->fail(T3_E_NOTFOUND, std::string("unknown tensor ") + name);   // cond_enc.*, text_head.*, tfmr.embed_tokens.* ...
 }
@@ -517,7 +517,7 @@ static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec&
     }
     if (n_sel > 0) {
         // final RMSNorm folded into the speech-head GEMM, which gathers the sampled rows itself
-        { Prof p(e, K_HEAD, s); GemmArgs a{g.h, (const uint4*)e->head, 2 * n_sel, D, V, g.logits, VPAD, 4, e->norm, g.dm.sel_rows}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16, 4, true), s)); }
+        { Prof p(e, K_HEAD, s); GemmArgs a{g.h, (const uint4*)e->head, 2 * n_sel, D, V, g.logits, VPAD, 4, e->norm, g.dm.sel_rows, HEAD_TILES}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16, 4, true), s)); }
         { Prof p(e, K_SAMPLE, s); SampleArgs sa{g.logits, VPAD, g.dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, g.dm.out_tok, e->d_dbg, n_sel}; HIP_TRY(launch_sampler(sa, s)); }
     }
     return T3_OK;
@@ -605,7 +605,11 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
                 HIP_TRY(ce);
                 HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
                 (void)hipGraphDestroy(graph);
-                if (g.graphs.size() > 64) { for (auto& kv : g.graphs) (void)hipGraphExecDestroy(kv.second); g.graphs.clear(); }
+                if (g.graphs.size() > 64) {          // a replay of one of them may still be running (run-ahead): drain first
+                    HIP_TRY(hipStreamSynchronize(g.stream));
+                    for (auto& kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
+                    g.graphs.clear();
+                }
                 it = g.graphs.emplace(key, exec).first;
             }
             HIP_TRY(hipGraphLaunch(it->second, g.stream));

@@ -8,6 +8,7 @@
 namespace t3 {
 
 constexpr int D = 1024, H = 16, HD = 64, F = 4096, V = 8194, VPAD = 8208, QKV = 3072;
+constexpr int HEAD_TILES = 516;                   // speech head packed to a multiple of 4 n-tiles (513 hold rows)
 constexpr int CHUNK = 64;                          // attention chunk in tokens (numerics contract)
 #ifndef T3_KV_BLOCK
 #define T3_KV_BLOCK 256
@@ -32,6 +33,7 @@ struct GemmArgs {
     int nw;              // waves = K segments per workgroup: 4 (qkv, gate/up, head) or 16 (o_proj, down_proj)
     const uint16_t* ln_w;    // non-null: fold RMSNorm with this weight [1024] into the GEMM (K = 1024, nw = 4)
     const int* row_index;    // optional gather: source row of X per GEMM row (speech head over the sampled rows)
+    int packed_tiles = 0;    // > 0: the packed weight holds this many n-tiles (zero rows beyond N), so tile groups may overhang N
 };
 
 // Host-side packing of a [N][K] bf16 matrix into MFMA-B-operand order:

@@ -330,12 +330,13 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
     // activations cost as much L2 -> CU traffic as the weights (in-kernel stamps, tools/gemm_clk.hip: the wait for the first
     // operand tile was 4.2 us against 2.1 us with that traffic removed).  More n-tiles per workgroup divide it, as long as the
     // grid stays wide enough: measured at 64 rows, qkv 768 -> 192 workgroups -0.95 us, gate/up 512 -> 256 -0.85 us; the
-    // 16-wave form loses (its reduction grows), the gathered head form keeps one tile (its last tile is partial).
+    // 16-wave form loses (its reduction grows).  A weight whose last tile is partial (the speech head: 513 tiles) takes part
+    // when its packed buffer was padded to a multiple of the tile group (GemmArgs::packed_tiles).
     int nt = epi == EPI_SILU ? 2 : 1;
-    if (norm && !a.row_index && epi != EPI_F32) {
+    if (norm && epi != EPI_F32 && (!a.row_index || a.packed_tiles > 0)) {
         static int force = -1;
         if (force < 0) { const char* e = getenv("T3_GEMM_NT"); force = e ? atoi(e) : 0; }
-        const int ntiles = (a.N + 15) / 16 * (epi == EPI_SILU ? 2 : 1);      // packed weight tiles
+        const int ntiles = a.packed_tiles > 0 ? a.packed_tiles : (a.N + 15) / 16 * (epi == EPI_SILU ? 2 : 1);      // packed weight tiles
         const int groups = ((a.M + 15) / 16 + mt - 1) / mt;
         const int want = epi == EPI_SILU ? 256 : 192;
         for (int c = 4; c > nt; c >>= 1)
