@@ -187,6 +187,27 @@ def test_long_prompt_many_blocks(E, oracle, tiny_weights, cond):
     m.close(); eng.close()
 
 
+def test_many_batch_shapes_graph_cache_turnover(E, oracle, tiny_weights, tiny_oracle, cond):
+    """150 short utterances through 72 slots: the number of running utterances sweeps 72 -> 0, so more than 64 distinct
+    decode-step shapes are captured and the graph cache is turned over while the run-ahead step is in flight."""
+    eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=120, max_seqs=72, kv_bytes=1 << 30, enforce_eager=False)
+    eng.load_tensors(tiny_weights); eng.finalize()
+    rs = np.random.RandomState(5)
+    reqs = []
+    for i in range(150):
+        prompt = make_prompt(int(rs.randint(3, 14)), seed=300 + i)
+        kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=4, uid=i, max_tokens=int(rs.randint(2, 60)), ignore_eos=True)
+        reqs.append((i, prompt, kw)); eng.add_request(i, prompt, cond, E.make_sampling(**kw))
+    eng.run_until_done()
+    for i, prompt, kw in reqs[::13]:
+        want, _ = tiny_oracle.generate(prompt, cond, oracle.make_sampling(**kw), max_model_len=120)
+        assert [t - 2500 for t in eng.get_output(i)[0]] == want, f"utterance {i}"
+    assert all(len(eng.get_output(i)[0]) == kw["max_tokens"] for i, _, kw in reqs)
+    st = eng.stats()
+    assert st.kv_blocks_free == st.kv_blocks_total
+    eng.close()
+
+
 def test_chunked_prefill_equals_whole(E, tiny_weights, cond):
     """A row budget smaller than one prompt forces the prompt through several steps; ids must not change."""
     outs = []
