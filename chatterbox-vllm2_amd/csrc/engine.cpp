@@ -94,6 +94,7 @@ struct T3Engine {
     struct Group {
         hipStream_t stream = nullptr;
         uint16_t *h = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *act = nullptr, *logits = nullptr;
+        float* rstd = nullptr;     // row statistic of the prefill-sized NORM GEMMs
         char *h_meta[2] = {nullptr, nullptr}, *d_meta = nullptr;     // host staging is double-buffered: step N+1 is built while N runs
         size_t meta_bytes = 0, meta_rows_off = 0;
         Meta hm[2]{}, dm{};
@@ -200,7 +201,7 @@ extern "C" int t3_destroy(T3Handle e) {
     for (auto& g : e->groups) {
         if (g.stream) (void)hipStreamSynchronize(g.stream);
         for (auto& kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
-        free_dev(g.h); free_dev(g.qkv); free_dev(g.qrot); free_dev(g.att); free_dev(g.act); free_dev(g.logits);
+        free_dev(g.h); free_dev(g.qkv); free_dev(g.qrot); free_dev(g.att); free_dev(g.act); free_dev(g.logits); free_dev(g.rstd);
         free_dev(g.d_meta); free_dev(g.dm.out_tok);
         for (int b = 0; b < 2; ++b) {
             if (g.h_meta[b]) (void)hipHostFree(g.h_meta[b]);
@@ -357,6 +358,7 @@ extern "C" int t3_finalize_weights(T3Handle e) {
         if ((rc = dalloc(e, &g.att, R * D, true))) return rc;
         if ((rc = dalloc(e, &g.act, R * F, true))) return rc;
         if ((rc = dalloc(e, &g.logits, 2 * Sg * VPAD, true))) return rc;
+        if ((rc = dalloc(e, &g.rstd, R, true))) return rc;
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
         const size_t o_selr = carve(2 * Sg * 4), o_sel = carve(Sg * 16), o_rows = carve(R * (size_t)e->row_stride * 4);
@@ -501,7 +503,7 @@ static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec&
         LayerW& y = e->layers[L];
         uint16_t* kvL = e->kv + (size_t)L * layer_elems;
         // 5 launches per layer: RMSNorm is folded into the qkv / gate-up GEMMs, the residual add into the o / down GEMMs
-        { Prof p(e, K_QKV, s); GemmArgs a{g.h, (const uint4*)y.qkv, M, D, QKV, g.qkv, QKV, 4, y.ln1, nullptr}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s)); }
+        { Prof p(e, K_QKV, s); GemmArgs a{g.h, (const uint4*)y.qkv, M, D, QKV, g.qkv, QKV, 4, y.ln1, nullptr, 0, g.rstd}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s)); }
         if (sr.n_prefill_rows == 0 && e->fuse_rope) {
             // decode-only step: every row is the newest position of its stream -> RoPE + KV write inside the attention kernel
             Prof p(e, K_ATTN, s);
@@ -512,7 +514,7 @@ static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec&
             { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot, kvL, g.dm.rows, e->row_stride, g.att, M, max_chunks, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(launch_attention(aa, s)); }
         }
         { Prof p(e, K_O, s); GemmArgs a{g.att, (const uint4*)y.o, M, D, D, g.h, D, 16, nullptr, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
-        { Prof p(e, K_GU, s); GemmArgs a{g.h, (const uint4*)y.gu, M, D, F, g.act, F, 4, y.ln2, nullptr}; HIP_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s)); }
+        { Prof p(e, K_GU, s); GemmArgs a{g.h, (const uint4*)y.gu, M, D, F, g.act, F, 4, y.ln2, nullptr, 0, g.rstd}; HIP_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s)); }
         { Prof p(e, K_DOWN, s); GemmArgs a{g.act, (const uint4*)y.down, M, F, D, g.h, D, 16, nullptr, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
     }
     if (n_sel > 0) {

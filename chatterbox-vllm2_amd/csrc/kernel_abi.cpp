@@ -59,7 +59,8 @@ extern "C" int t3k_norm_gemm(const void* h, const void* ln_w, const void* w, int
     K_TRY(dh.from(h, (size_t)Mh * D * 2)); K_TRY(dl.from(ln_w, D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2));
     K_TRY(dout.alloc((size_t)M * N * 4, true));
     if (row_index) K_TRY(dri.from(row_index, (size_t)M * 4));
-    GemmArgs a{dh.as<uint16_t>(), dw.as<uint4>(), M, D, N, dout.p, N, 4, dl.as<uint16_t>(), row_index ? dri.as<int>() : nullptr};
+    DevBuf drs; K_TRY(drs.alloc((size_t)M * 4));
+    GemmArgs a{dh.as<uint16_t>(), dw.as<uint4>(), M, D, N, dout.p, N, 4, dl.as<uint16_t>(), row_index ? dri.as<int>() : nullptr, 0, drs.as<float>()};
     K_TRY(launch_gemm(a, EPI_F32, choose_mt(M, Npad / 16, 4, true), nullptr));
     K_TRY(hipDeviceSynchronize());
     K_TRY(hipMemcpy(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
@@ -89,7 +90,8 @@ extern "C" int t3k_silu_mul_gemm(const void* h, const void* ln_w, const void* wg
     pack_gate_up((const uint16_t*)wg, (const uint16_t*)wu, Fd, D, packed.data());
     DevBuf dx, dl, dw, dout;
     K_TRY(dx.from(h, (size_t)M * D * 2)); K_TRY(dl.from(ln_w, D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * Fd * 2, true));
-    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, D, Fd, dout.p, Fd, 4, dl.as<uint16_t>(), nullptr};
+    DevBuf drs; K_TRY(drs.alloc((size_t)M * 4));
+    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, D, Fd, dout.p, Fd, 4, dl.as<uint16_t>(), nullptr, 0, drs.as<float>()};
     K_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, Fd / 16, 4, true), nullptr));
     K_TRY(hipDeviceSynchronize());
     K_TRY(hipMemcpy(out, dout.p, (size_t)M * Fd * 2, hipMemcpyDeviceToHost));

@@ -34,6 +34,7 @@ struct GemmArgs {
     const uint16_t* ln_w;    // non-null: fold RMSNorm with this weight [1024] into the GEMM (K = 1024, nw = 4)
     const int* row_index;    // optional gather: source row of X per GEMM row (speech head over the sampled rows)
     int packed_tiles = 0;    // > 0: the packed weight holds this many n-tiles (zero rows beyond N), so tile groups may overhang N
+    float* rstd_scratch = nullptr;   // [M] floats: lets the NORM forms take the prefill-sized schedule (row statistic in its own pass)
 };
 
 // Host-side packing of a [N][K] bf16 matrix into MFMA-B-operand order:

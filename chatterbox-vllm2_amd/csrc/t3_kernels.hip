@@ -277,6 +277,165 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     T3_GSTAMP(4);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Prefill-sized GEMM (M >= 256 rows): the same numbers as gemm_kernel, another schedule.  A workgroup of four waves owns a
+// 128-row x 64-column tile (4 packed n-tiles); every K step of 32 is staged once through LDS (activations 128 x 64 B row
+// pieces -- RMSNorm weight applied on the way in; weights: 4 packed 1 KiB fragments) and feeds 32 MFMAs, so a weight byte is
+// re-read once per 128 rows instead of once per 32 and an activation byte once per 64 columns instead of once per workgroup.
+// Contract order per output: one MFMA chain per K segment FROM ZERO in ascending k; segments folded left to right in groups
+// of four (G = ((s0 + s1) + s2) + s3), groups folded left to right -- hence three accumulator sets (segment, group, total).
+// The row statistic of the NORM forms comes from row_rstd_kernel (same partial sums as gemm_kernel's own).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_rstd_kernel(const uint16_t* h, float* rstd, int rows) {
+    // 16 lanes per row: lane (s = segment of 256, q = lane group of the A fragment) adds h^2 over k = 256 s + 32 kb + 8 q + j
+    const int lane = threadIdx.x & 63, l16 = lane & 15, sg = l16 >> 2, q = l16 & 3;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const int rr = row < rows ? row : rows - 1;
+    const uint16_t* hr = h + (size_t)rr * D + sg * 256 + q * 8;
+    float a = 0.0f;
+    for (int kb = 0; kb < 8; ++kb) {
+        float xf[8]; unpack8(*reinterpret_cast<const uint4*>(hr + kb * 32), xf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a = __builtin_fmaf(xf[e], xf[e], a);
+    }
+    a = a + __shfl_xor(a, 1); a = a + __shfl_xor(a, 2);          // over q: (p0 + p1) + (p2 + p3)
+    const float s0 = __shfl(a, (lane & 48) + 0), s1 = __shfl(a, (lane & 48) + 4), s2 = __shfl(a, (lane & 48) + 8), s3 = __shfl(a, (lane & 48) + 12);
+    const float ss = ((s0 + s1) + s2) + s3;
+    if (l16 == 0 && row < rows) rstd[row] = 1.0f / sqrtf(ss * (1.0f / 1024.0f) + 1e-5f);
+}
+
+template <int EPI, int NSEG, bool NORM>
+__global__ __launch_bounds__(256) void pgemm_kernel(GemmArgs a, const float* rstd) {
+    __shared__ __attribute__((aligned(16))) uint4 As[2][512], Bs[2][256];     // per stage: 128 rows x 64 B; 4 fragments x 1 KiB
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;                                   // wave tile: rows 64 wr .., packed n-tiles 2 wc, 2 wc + 1
+    const int KB = a.K >> 5, kbs = KB / NSEG;
+    const int m0 = blockIdx.y * 128, nt0 = blockIdx.x * 4;
+    // staging assignment: two activation pieces (row, q) and one weight piece per thread
+    const uint4* xsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pce = t + 256 * j, row = pce >> 2, q = pce & 3;
+        int m = m0 + row; m = m < a.M ? m : a.M - 1;
+        xsrc[j] = reinterpret_cast<const uint4*>(a.X + (size_t)m * a.K + q * 8);
+    }
+    const uint4* lnsrc = NORM ? reinterpret_cast<const uint4*>(a.ln_w + (t & 3) * 8) : nullptr;
+    const uint4* wsrc = a.Wp + ((size_t)(nt0 + (t >> 6)) * KB) * 64 + lane;
+    uint4 xa[2], wb, lw;
+    auto fetch = [&](int kb) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xa[j] = xsrc[j][kb * 4];
+        wb = ld_nt(wsrc + (size_t)kb * 64);
+        if (NORM) lw = lnsrc[kb * 4];
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint4 v = xa[j];
+            if constexpr (NORM) {
+                float xf[8], lf[8]; unpack8(v, xf); unpack8(lw, lf);
+                v.x = cvt_pk(xf[0] * lf[0], xf[1] * lf[1]); v.y = cvt_pk(xf[2] * lf[2], xf[3] * lf[3]);
+                v.z = cvt_pk(xf[4] * lf[4], xf[5] * lf[5]); v.w = cvt_pk(xf[6] * lf[6], xf[7] * lf[7]);
+            }
+            As[buf][t + 256 * j] = v;
+        }
+        Bs[buf][t] = wb;
+    };
+    f32x4 sg[4][2], gr[4][2], tot[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { sg[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f}; gr[i][u] = sg[i][u]; tot[i][u] = sg[i][u]; }
+
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int kin = 0, seg = 0;
+    for (int kb = 0; kb < KB; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < KB) fetch(kb + 1);
+        uint4 af[4], bf[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = As[buf][(wr * 64 + i * 16 + (lane & 15)) * 4 + (lane >> 4)];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) bf[u] = Bs[buf][(wc * 2 + u) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(bf[u]), sg[i][u], 0, 0, 0);
+        if (++kin == kbs) {                      // segment complete: fold it
+            const bool first_in_group = (seg & 3) == 0, last_in_group = (seg & 3) == 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gr[i][u][r] = first_in_group ? sg[i][u][r] : gr[i][u][r] + sg[i][u][r];
+                        if (NSEG > 4 && last_in_group) tot[i][u][r] = seg == 3 ? gr[i][u][r] : tot[i][u][r] + gr[i][u][r];
+                        sg[i][u][r] = 0.0f;
+                    }
+                }
+            kin = 0; ++seg;
+        }
+        if (kb + 1 < KB) stage(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: D[row = 4 (lane >> 4) + r][col = lane & 15] of every 16 x 16 tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wr * 64 + i * 16 + 4 * (lane >> 4) + r;
+            if (m >= a.M) continue;
+            float v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) v[u] = NSEG > 4 ? tot[i][u][r] : gr[i][u][r];
+            if constexpr (NORM) { const float rs = rstd[m]; v[0] = v[0] * rs; v[1] = v[1] * rs; }
+            if constexpr (EPI == EPI_SILU) {
+                const int n = ((nt0 >> 1) + wc) * 16 + (lane & 15);          // packed pair (gate, up) -> one output tile
+                if (n < a.N) reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)silu_mul_bf(f2bf(v[0]), f2bf(v[1]));
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int n = (nt0 + wc * 2 + u) * 16 + (lane & 15);
+                    if (n >= a.N) continue;
+                    if constexpr (EPI == EPI_F32) {
+                        reinterpret_cast<float*>(a.out)[(size_t)m * a.ldo + n] = v[u];
+                    } else {
+                        uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
+                        if constexpr (EPI == EPI_BF16) *op = (uint16_t)f2bf(v[u]);
+                        else *op = (uint16_t)f2bf(bf2f(*op) + rbf(v[u]));     // EPI_RESID: h = bf16(h + bf16(y))
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Large-M path of launch_gemm: returns hipErrorNotSupported when the shape is not one of the layer forms.
+static hipError_t launch_pgemm(const GemmArgs& a, int epi, hipStream_t s) {
+    const bool norm = a.ln_w != nullptr;
+    const int nseg = a.nw == 16 ? 16 : 4;
+    const int ntiles = (a.N + 15) / 16 * (epi == EPI_SILU ? 2 : 1);
+    if (a.row_index || ntiles % 4 || a.K % (32 * nseg) || (norm && (!a.rstd_scratch || a.K != D))) return hipErrorNotSupported;
+    const dim3 grid(ntiles / 4, (a.M + 127) / 128);
+    if (norm) {
+        hipLaunchKernelGGL(row_rstd_kernel, dim3((a.M + 15) / 16), dim3(256), 0, s, a.X, a.rstd_scratch, a.M);
+        if (epi == EPI_BF16) hipLaunchKernelGGL((pgemm_kernel<EPI_BF16, 4, true>), grid, dim3(256), 0, s, a, (const float*)a.rstd_scratch);
+        else if (epi == EPI_F32) hipLaunchKernelGGL((pgemm_kernel<EPI_F32, 4, true>), grid, dim3(256), 0, s, a, (const float*)a.rstd_scratch);
+        else if (epi == EPI_SILU) hipLaunchKernelGGL((pgemm_kernel<EPI_SILU, 4, true>), grid, dim3(256), 0, s, a, (const float*)a.rstd_scratch);
+        else return hipErrorNotSupported;
+    } else {
+        if (epi == EPI_RESID && nseg == 16) hipLaunchKernelGGL((pgemm_kernel<EPI_RESID, 16, false>), grid, dim3(256), 0, s, a, (const float*)nullptr);
+        else if (epi == EPI_F32 && nseg == 16) hipLaunchKernelGGL((pgemm_kernel<EPI_F32, 16, false>), grid, dim3(256), 0, s, a, (const float*)nullptr);
+        else if (epi == EPI_F32) hipLaunchKernelGGL((pgemm_kernel<EPI_F32, 4, false>), grid, dim3(256), 0, s, a, (const float*)nullptr);
+        else return hipErrorNotSupported;
+    }
+    return hipGetLastError();
+}
+
 int choose_mt(int M, int ntiles_x, int nw, bool norm) {
     const int mtiles = (M + 15) / 16;
     if (const char* e = getenv("T3_GEMM_MT")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) return v; }
@@ -326,6 +485,14 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
     const bool norm = a.ln_w != nullptr;
     if (a.K % (32 * nw) != 0 || (norm && (a.K != D || nw != 4))) return hipErrorInvalidValue;
     if (nw == 16 && mt > 4) mt = 4;               // LDS: 16 waves x MT x 1 KiB x 4
+    {
+        static int pg_min = -1;                   // rows from which the LDS-tiled schedule takes over (0 = never)
+        if (pg_min < 0) { const char* e = getenv("T3_PGEMM_MIN_ROWS"); pg_min = e ? atoi(e) : 256; }
+        if (pg_min > 0 && a.M >= pg_min) {
+            const hipError_t pe = launch_pgemm(a, epi, s);
+            if (pe != hipErrorNotSupported) return pe;
+        }
+    }
     // n-tiles per workgroup (NORM forms).  Every workgroup re-reads its rows of the activation operand, so at 64 rows the
     // activations cost as much L2 -> CU traffic as the weights (in-kernel stamps, tools/gemm_clk.hip: the wait for the first
     // operand tile was 4.2 us against 2.1 us with that traffic removed).  More n-tiles per workgroup divide it, as long as the

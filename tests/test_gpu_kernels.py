@@ -68,6 +68,25 @@ def test_norm_folded_gemm_bit_exact(E, oracle, M, N):
     assert (got.double() - ref).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M", [256, 300, 515])
+def test_prefill_sized_gemms_bit_exact(E, oracle, M):
+    """From 256 rows on the LDS-tiled schedule (pgemm_kernel, 128 x 64 workgroup tiles, row statistic in its own pass) takes
+    over; the numbers must not change: every form against the same oracle functions, ragged row counts."""
+    x = rand_bf16(M, 1024, seed=M, scale=1.5); W = rand_bf16(128, 1024, seed=11, scale=0.05)
+    assert_bit_equal(E.k_gemm(x, W), oracle.gemm(x, W), f"4-segment gemm M={M}")
+    assert_bit_equal(E.k_gemm(x, W[:64], nw=16), oracle.gemm(x, W[:64], 64), f"16-segment gemm K=1024 M={M}")
+    x4 = rand_bf16(M, 4096, seed=M + 1); W4 = rand_bf16(64, 4096, seed=12, scale=0.05)
+    assert_bit_equal(E.k_gemm(x4, W4, nw=16), oracle.gemm(x4, W4, 256), f"16-segment gemm K=4096 M={M}")
+    ln = (rand_bf16(1024, seed=9) + 1.0).to(torch.bfloat16)
+    assert_bit_equal(E.k_norm_gemm(x, ln, W), oracle.norm_gemm(x, ln, W), f"norm+gemm M={M}")
+    hres = rand_bf16(M, 64, seed=5, scale=2.0)
+    y = oracle.gemm(x4, W4, 256).to(torch.bfloat16)
+    assert_bit_equal(E.k_gemm_resid(x4, W4, hres), (hres.float() + y.float()).to(torch.bfloat16), f"residual epilogue M={M}")
+    Wg = rand_bf16(64, 1024, seed=2, scale=0.1); Wu = rand_bf16(64, 1024, seed=3, scale=0.1)
+    g = oracle.norm_gemm(x, ln, Wg).to(torch.bfloat16); u = oracle.norm_gemm(x, ln, Wu).to(torch.bfloat16)
+    assert_bit_equal(E.k_silu_mul_gemm(x, ln, Wg, Wu), oracle.silu_mul(g, u), f"gate/up SiLU M={M}")
+
+
 def test_norm_folded_gemm_row_gather(E, oracle):
     h = rand_bf16(50, 1024, seed=1, scale=2.0); ln = (rand_bf16(1024, seed=2) + 1.0).to(torch.bfloat16); W = rand_bf16(160, 1024, seed=3, scale=0.05)
     idx = [49, 0, 7, 7, 31, 12]
