@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void row_rstd_kernel(const uint16_t* h, float*
 }
 
 template <int EPI, int NSEG, bool NORM>
-__global__ __launch_bounds__(256) void pgemm_kernel(GemmArgs a, const float* rstd) {
+__global__ __launch_bounds__(256, NSEG == 4 ? 4 : 2) void pgemm_kernel(GemmArgs a, const float* rstd) {
     __shared__ __attribute__((aligned(16))) uint4 As[2][512], Bs[2][256];     // per stage: 128 rows x 64 B; 4 fragments x 1 KiB
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;                                   // wave tile: rows 64 wr .., packed n-tiles 2 wc, 2 wc + 1
