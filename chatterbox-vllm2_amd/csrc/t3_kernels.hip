@@ -414,6 +414,9 @@ __global__ __launch_bounds__(256, NSEG == 4 ? 4 : 2) void pgemm_kernel(GemmArgs 
     }
 }
 
+static int g_pgemm_min_rows = -1;
+void set_pgemm_min_rows(int rows) { g_pgemm_min_rows = rows; }
+
 // Large-M path of launch_gemm: returns hipErrorNotSupported when the shape is not one of the layer forms.
 static hipError_t launch_pgemm(const GemmArgs& a, int epi, hipStream_t s) {
     const bool norm = a.ln_w != nullptr;
@@ -486,8 +489,11 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
     if (a.K % (32 * nw) != 0 || (norm && (a.K != D || nw != 4))) return hipErrorInvalidValue;
     if (nw == 16 && mt > 4) mt = 4;               // LDS: 16 waves x MT x 1 KiB x 4
     {
-        static int pg_min = -1;                   // rows from which the LDS-tiled schedule takes over (0 = never)
-        if (pg_min < 0) { const char* e = getenv("T3_PGEMM_MIN_ROWS"); pg_min = e ? atoi(e) : 256; }
+        // rows from which the LDS-tiled schedule takes over (0 = never).  1024: a 256-row call is a DECODE step of 128 utterances,
+        // where 128 x 64 tiles leave 32-128 workgroups (measured on the continuous-batching run of tools/bench_serving.py:
+        // 16.8 k tok/s with the switch at 256 rows, 25.0 k at 1024 or 2048).
+        if (g_pgemm_min_rows < 0) { const char* e = getenv("T3_PGEMM_MIN_ROWS"); g_pgemm_min_rows = e ? atoi(e) : 1024; }
+        const int pg_min = g_pgemm_min_rows;
         if (pg_min > 0 && a.M >= pg_min) {
             const hipError_t pe = launch_pgemm(a, epi, s);
             if (pe != hipErrorNotSupported) return pe;

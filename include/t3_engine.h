@@ -198,6 +198,9 @@ int t3k_rope_attention(const void* qkv_bf16, const int32_t* row_stream, const in
 int t3k_sample(const void* logits2_bf16, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg,
                uint32_t step, int32_t* token_out, float* logits_out_8194 /*nullable*/);
 int t3k_expf(const float* x, float* y, int32_t n);
+/* Row count from which the GEMM launcher switches to its prefill schedule (same numbers, LDS-tiled); process-wide.
+ * < 0 restores the default (1024).  For the parity tests, which check the prefill schedule at small row counts. */
+int t3k_set_prefill_rows(int32_t rows);
 
 #ifdef __cplusplus
 }

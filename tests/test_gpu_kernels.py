@@ -70,8 +70,16 @@ def test_norm_folded_gemm_bit_exact(E, oracle, M, N):
 
 @pytest.mark.parametrize("M", [256, 300, 515])
 def test_prefill_sized_gemms_bit_exact(E, oracle, M):
-    """From 256 rows on the LDS-tiled schedule (pgemm_kernel, 128 x 64 workgroup tiles, row statistic in its own pass) takes
-    over; the numbers must not change: every form against the same oracle functions, ragged row counts."""
+    """The LDS-tiled prefill schedule (pgemm_kernel, 128 x 64 workgroup tiles, row statistic in its own pass) must not
+    change the numbers: every form against the same oracle functions, ragged row counts."""
+    E.k_set_prefill_rows(256)                        # the engine switches at 1024 rows; here the schedule is checked on small cases
+    try:
+        _prefill_sized_checks(E, oracle, M)
+    finally:
+        E.k_set_prefill_rows(-1)
+
+
+def _prefill_sized_checks(E, oracle, M):
     x = rand_bf16(M, 1024, seed=M, scale=1.5); W = rand_bf16(128, 1024, seed=11, scale=0.05)
     assert_bit_equal(E.k_gemm(x, W), oracle.gemm(x, W), f"4-segment gemm M={M}")
     assert_bit_equal(E.k_gemm(x, W[:64], nw=16), oracle.gemm(x, W[:64], 64), f"16-segment gemm K=1024 M={M}")
