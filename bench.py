@@ -6,13 +6,21 @@ Workload (config.workload = "C3"): multilingual vocab 2454, B = 32 utterances pe
 synthetic weights (no checkpoint offline), the reference's sampling defaults (temperature 0.8, top-p 0.8,
 repetition penalty 2.0, tts.py:377,416) with the stop id masked (fixed-length generation).
 A "step" = one pass of the hot path over the batch = one decode step of all 32 utterances (64 CFG rows).
-Prefill and warmup steps are outside the timed region; inputs (weights, prompts, KV) are resident in HBM.
+Prefill, fast-forward and warmup steps are outside the timed region; inputs (weights, prompts, KV) are resident in HBM.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+The K timed steps are CENTRED on the middle of the utterances' lives (decode step (max_model_len - longest prompt) / 2, where the
+context equals the whole-run mean, ~560 tokens for C3) whatever K is: the engine is fast-forwarded with untimed decode steps
+first, so `--steps 20` and `--steps 800` measure the same operating point (config.ctx_first / ctx_last say which).
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1: one rank per GPU over RCCL.  Launched without WORLD_SIZE in the environment, this process starts the N ranks itself
+(`python -m torch.distributed.run ... bench.py`, before it touches the GPU) and relays rank 0's JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,6 +44,48 @@ def parse():
     return ap.parse_args()
 
 
+T_EN, T_ES = 116, 141             # prompt lengths of the two C3 utterances
+
+
+def plan_window(args):
+    """(fast-forward steps, first timed decode step, last timed decode step + 1): the timed window is centred on the run midpoint."""
+    g_min = args.max_model_len - T_ES - 3                 # decode steps every utterance of the batch can take
+    if args.steps + args.warmup > g_min:
+        sys.exit(f"steps + warmup must be <= {g_min} for this workload")
+    centre = (args.max_model_len - T_ES) // 2
+    ff = max(0, min(centre - args.steps // 2 - args.warmup, g_min - args.steps - args.warmup))
+    first = 1 + ff + args.warmup                         # the prefill step samples token 0
+    return ff, first, first + args.steps
+
+
+def workload_string(args, first, last):
+    b_en = args.batch // 2
+    is_c3 = (args.batch, args.max_model_len, args.layers) == (32, 1000, 30)
+    tag = "C3" if is_c3 else "custom (NOT a BASELINE.json config)"
+    return (f"{tag}: t3-model-multilingual ({args.layers}-layer Llama_520M, vocab 2454), {b_en} en (T={T_EN}) + {args.batch - b_en} es (T={T_ES}) "
+            f"utterances per GPU, max_model_len={args.max_model_len}, CFG dual stream ({2 * args.batch} rows/step), temperature 0.8 / top-p 0.8 / "
+            f"repetition penalty 2.0, stop id masked; timed window = decode steps [{first}, {last}) of every utterance")
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks as children (nothing in this process has touched the GPU) and relay rank 0."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    sys.exit(p.returncode if p.returncode else (0 if line else 1))
+
+
 def build_requests(E, args, rank):
     from chatterbox_vllm2_amd.prompt import assemble_prompt_ids
     tok = json.load(open(os.path.join(ROOT, "tests", "golden", "tokenizer.json")))
@@ -50,8 +100,8 @@ def build_requests(E, args, rank):
     return reqs
 
 
-def run_pass(eng, reqs, cond, warmup, steps, sync, profile=False):
-    """prefill (untimed) -> warmup decode steps -> barrier -> K timed decode steps -> barrier.  Returns dict."""
+def run_pass(eng, reqs, cond, ff, warmup, steps, sync, profile=False, only=None):
+    """prefill (untimed) -> fast-forward + warmup decode steps -> barrier -> K timed decode steps -> barrier.  Returns dict."""
     import torch
     for rid, prompt, sp in reqs:
         eng.add_request(rid, prompt, cond, sp)
@@ -63,8 +113,8 @@ def run_pass(eng, reqs, cond, warmup, steps, sync, profile=False):
             break
     torch.cuda.synchronize()
     prefill_s = time.perf_counter() - t0
-    assert eng.run_steps(warmup) == warmup
-    eng.set_profile(profile)
+    assert eng.run_steps(ff + warmup) == ff + warmup
+    eng.set_profile(profile, only)
     eng.reset_stats()
     sync()
     t0 = time.perf_counter()
@@ -73,7 +123,7 @@ def run_pass(eng, reqs, cond, warmup, steps, sync, profile=False):
     dt = time.perf_counter() - t0
     sync()
     eng.set_profile(False)
-    assert done == steps, f"only {done} of {steps} steps ran (steps + warmup must stay below max_model_len - longest prompt)"
+    assert done == steps, f"only {done} of {steps} steps ran (fast-forward + warmup + steps must stay below max_model_len - longest prompt)"
     st = eng.stats()
     assert st.decode_steps == steps and st.tokens_generated == steps * len(reqs)
     kern = {k: eng.kernel_ms(k) for k in __import__("chatterbox_vllm2_amd.engine", fromlist=["x"]).KERNEL_CLASSES} if profile else {}
@@ -103,6 +153,9 @@ def cpu_baseline(weights, args):
 
 def main():
     args = parse()
+    ff, first, last = plan_window(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     import torch
     import torch.distributed as dist
 
@@ -110,9 +163,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs one rank per GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
-                     f"--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus {args.gpus} ...")
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the T3 engine has no CPU path")
@@ -136,9 +186,6 @@ def main():
     from chatterbox_vllm2_amd import engine as E
     from chatterbox_vllm2_amd.weights import synthetic_cond_emb, synthetic_tensors
 
-    longest = 141
-    if args.steps + args.warmup > args.max_model_len - longest - 3:
-        sys.exit(f"steps + warmup must be <= {args.max_model_len - longest - 3} for this workload")
     weights = list(synthetic_tensors(args.layers, 2454, 1234))
     cond = synthetic_cond_emb(1)
     eng = E.T3Engine(n_layers=args.layers, text_vocab=2454, max_model_len=args.max_model_len, max_seqs=args.batch,
@@ -146,16 +193,21 @@ def main():
     eng.load_tensors(weights); eng.finalize()
     reqs = build_requests(E, args, rank)
 
-    res = run_pass(eng, reqs, cond, args.warmup, args.steps, sync, profile=False)
+    res = run_pass(eng, reqs, cond, ff, args.warmup, args.steps, sync, profile=False)
     t = torch.tensor([res["dt"]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     st = res["stats"]
 
-    prof = None
+    prof = dom_only = None
     if rank == 0 and not args.no_profile_pass:
-        prof = run_pass(eng, reqs, cond, args.warmup, args.steps, lambda: torch.cuda.synchronize(), profile=True)
+        # pass 2: HIP events around every kernel class (eager launches) -> which class dominates, and the per-class table;
+        # pass 3: events around the dominant class only, the rest of the step undisturbed -> its average launch duration
+        nsync = lambda: torch.cuda.synchronize()
+        prof = run_pass(eng, reqs, cond, ff, args.warmup, args.steps, nsync, profile=True)
+        tot = {k: v[0] * v[1] for k, v in prof["kern"].items()}
+        dom_only = run_pass(eng, reqs, cond, ff, args.warmup, args.steps, nsync, profile=True, only=max(tot, key=tot.get))
     if world > 1:
         dist.barrier()
     eng.close()
@@ -168,9 +220,10 @@ def main():
             "metric": "speech-tokens/sec/GPU (T3 decode, batch=32) + p50 RTF", "value": round(value, 2), "unit": "speech-tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "C3: t3-model-multilingual (30-layer Llama_520M, vocab 2454), 16 en (T=116) + 16 es (T=141) utterances per GPU, "
-                                   "max_model_len=1000, CFG dual stream (64 rows/step), temperature 0.8 / top-p 0.8 / repetition penalty 2.0, stop id masked",
-                       "batch_per_gpu": args.batch, "global_batch": world * args.batch, "max_model_len": args.max_model_len,
+            "config": {"workload": workload_string(args, first, last),
+                       "ctx_first": round((T_EN * (args.batch // 2) + T_ES * (args.batch - args.batch // 2)) / args.batch + first, 1),
+                       "ctx_last": round((T_EN * (args.batch // 2) + T_ES * (args.batch - args.batch // 2)) / args.batch + last - 1, 1),
+                       "fast_forward_steps": ff, "batch_per_gpu": args.batch, "global_batch": world * args.batch, "max_model_len": args.max_model_len,
                        "layers": args.layers, "parallelism": f"dp{world} (utterance shards, no collective inside a step)",
                        "weights": "seeded synthetic N(0,0.02^2), seed 1234"},
             "tokens_per_s_per_gpu": round(value / world, 2),
@@ -190,7 +243,7 @@ def main():
                 algo = pst.sum_ctx_decode / pst.decode_steps * KV_BYTES_TOK_STREAM_LAYER
             else:
                 algo = wbytes.get(dom, 0)
-            ms = kern[dom][0]
+            ms = dom_only["kern"][dom][0]                  # events around this class only
             # HBM bytes per launch from the PMC pass recorded in profiles/traffic.json (FETCH_SIZE, gfx950 x2 correction):
             # the measured bytes/algorithmic-bytes ratio of that pass applied to this run's algorithmic bytes per launch
             traffic = None
@@ -202,7 +255,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "algo_bytes_per_launch": round(algo), "avg_launch_ms": round(ms, 5), "launches": kern[dom][1]}
-            out["kernel_ms_per_step"] = {k: round(tot[k] / pst.decode_steps, 4) for k in tot}
+            out["roofline"]["timing"] = "HIP events on the engine's stream around every launch of this kernel class in a pass of the same steps"
+            out["kernel_ms_per_step_all_classes_evented"] = {k: round(tot[k] / pst.decode_steps, 4) for k in tot}   # eager + 2 events per kernel: over-reports
             out["profiled_ms_per_step"] = round(prof["dt"] / args.steps * 1e3, 4)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(weights, args)

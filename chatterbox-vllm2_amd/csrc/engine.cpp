@@ -134,6 +134,7 @@ struct T3Engine {
     T3Stats st{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profile = false;
+    int profile_only = -1;     // >= 0: events around this kernel class only
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pev[K_COUNT];
     size_t pev_used[K_COUNT] = {0};
     double k_ms[K_COUNT] = {0};
@@ -428,6 +429,11 @@ extern "C" int t3_add_request(T3Handle e, int64_t req_id, const int32_t* ids, in
     if (sp->max_tokens <= 0) return e->fail(T3_E_INVALID, "max_tokens must be positive");
     if (!(sp->temperature >= 0.0f) || !(sp->top_p > 0.0f && sp->top_p <= 1.0f) || !(sp->min_p >= 0.0f && sp->min_p <= 1.0f) || !(sp->repetition_penalty > 0.0f))
         return e->fail(T3_E_INVALID, "sampling parameter out of range");
+    // a NaN / Inf conditioning row would turn every logit into NaN (the sampler then has no mass to draw from)
+    for (size_t i = 0; i < (size_t)T3_COND_ROWS * D; ++i) {
+        uint32_t u; memcpy(&u, cond + i, 4);
+        if ((u & 0x7f800000u) == 0x7f800000u) return e->fail(T3_E_INVALID, "conditioning embedding contains a non-finite value");
+    }
     Request r;
     r.id = req_id; r.prompt.assign(ids, ids + T); r.cond.assign(cond, cond + (size_t)T3_COND_ROWS * D); r.sp = *sp;
     r.limit = std::min(sp->max_tokens, e->cfg.max_model_len - T);
@@ -478,7 +484,7 @@ static int admit(T3Engine* e) {
 struct Prof {
     T3Engine* e; int k; bool on; hipEvent_t a, b;
     hipStream_t st;
-    Prof(T3Engine* e_, int k_, hipStream_t st_) : e(e_), k(k_), on(e_->profile), st(st_) {
+    Prof(T3Engine* e_, int k_, hipStream_t st_) : e(e_), k(k_), on(e_->profile && (e_->profile_only < 0 || e_->profile_only == k_)), st(st_) {
         if (!on) return;
         auto& v = e->pev[k]; size_t& u = e->pev_used[k];
         if (u == v.size()) { hipEvent_t x, y; hipEventCreate(&x); hipEventCreate(&y); v.emplace_back(x, y); }
@@ -755,6 +761,25 @@ extern "C" int t3_release_request(T3Handle e, int64_t req_id) {
     return T3_OK;
 }
 
+extern "C" int t3_abort_request(T3Handle e, int64_t req_id) {
+    if (!e) return T3_E_INVALID;
+    auto it = e->reqs.find(req_id);
+    if (it == e->reqs.end()) return e->fail(T3_E_NOTFOUND, "unknown request id");
+    Request& r = it->second;
+    // a row of a finished request can only be on a stream inside a run loop, and those never return with work in flight
+    if (r.zombie) return e->fail(T3_E_STATE, "request has a step in flight");
+    if (r.state == WAITING) {
+        e->waiting.erase(std::remove(e->waiting.begin(), e->waiting.end(), req_id), e->waiting.end());
+    } else if (r.state != FINISHED) {
+        (void)hipSetDevice(e->cfg.device_id);
+        for (auto& g : e->groups) if (g.stream) (void)hipStreamSynchronize(g.stream);      // nothing of it may still be running
+        e->running.erase(std::remove(e->running.begin(), e->running.end(), req_id), e->running.end());
+        release_slot(e, r);
+    }
+    e->reqs.erase(it);
+    return T3_OK;
+}
+
 extern "C" int t3_debug_logits(T3Handle e, int64_t req_id, float* out) {
     if (!e || !out) return T3_E_INVALID;
     if (!e->d_dbg) return e->fail(T3_E_STATE, "engine was created without debug_logits");
@@ -775,6 +800,12 @@ extern "C" int t3_reset_stats(T3Handle e) {
     return T3_OK;
 }
 extern "C" int t3_set_profile(T3Handle e, int32_t on) { if (!e) return T3_E_INVALID; e->profile = on != 0; return T3_OK; }
+extern "C" int t3_set_profile_kernel(T3Handle e, const char* name) {
+    if (!e) return T3_E_INVALID;
+    if (!name || !*name) { e->profile_only = -1; return T3_OK; }
+    for (int k = 0; k < K_COUNT; ++k) if (!strcmp(name, kclass_names[k])) { e->profile_only = k; return T3_OK; }
+    return e->fail(T3_E_NOTFOUND, "unknown kernel class");
+}
 extern "C" int t3_kernel_ms(T3Handle e, const char* name, double* avg_ms, int64_t* launches) {
     if (!e || !name) return T3_E_INVALID;
     for (int k = 0; k < K_COUNT; ++k)

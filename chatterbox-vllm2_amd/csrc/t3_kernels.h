@@ -89,6 +89,22 @@ struct AttnArgs {
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
+// Persistent layer chain (chain_kernel.hip): o_proj(+residual) -> gate/up -> down_proj(+residual) -> next layer's qkv in one launch.
+constexpr int CHAIN_WGS = 256;                    // one workgroup per CU
+struct ChainArgs {
+    const uint4 *Wo, *Wgu, *Wd, *Wqkv;            // packed weights of this layer; Wqkv = the NEXT layer's qkv (phase bit 3)
+    const uint16_t *ln2, *ln1n;                   // this layer's post-attention norm weight, the next layer's input norm weight
+    const uint16_t* att;                          // [M][1024] attention output (previous launch)
+    uint16_t* h;                                  // [M][1024] residual stream, updated in place
+    uint16_t* act;                                // [M][4096] scratch
+    uint16_t* qkv;                                // [M][3072] out
+    int M;                                        // rows, <= 64
+    int phases;                                   // bit 0 o, bit 1 gate/up, bit 2 down, bit 3 qkv (executed in this order)
+    unsigned* flags;                              // [CHAIN_WGS] barrier epochs, zeroed once at allocation, never reset
+    unsigned* err;                                // set to 1 when a barrier wait gave up
+};
+hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
+
 struct SampleArgs {
     const uint16_t* logits;    // [2*n][ldl] bf16: row 2i cond, 2i+1 uncond
     int ldl;

@@ -11,65 +11,12 @@
 //   CFG logits ....... t3.py:650-673
 //   sampler .......... vllm SamplingParams as configured at src/chatterbox_vllm/tts.py:455-464
 #include "t3_kernels.h"
+#include "t3_device.h"
 
 #include <math.h>
 #include <string.h>
 
 namespace t3 {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// ------------------------------------------------------------------------------------------------
-// scalar helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
-// fp32 -> bf16 round-to-nearest-even, NaN stays quiet NaN
-__device__ __forceinline__ uint32_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-__device__ __forceinline__ float rbf(float f) { return __uint_as_float(f2bf(f) << 16); }
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
-
-// element j (0..7) of a 16-byte vector of 8 bf16, as fp32
-template <int J>
-__device__ __forceinline__ float elem(const uint4& v) {
-    const uint32_t w = (J >> 1) == 0 ? v.x : (J >> 1) == 1 ? v.y : (J >> 1) == 2 ? v.z : v.w;
-    return (J & 1) ? bf_hi(w) : bf_lo(w);
-}
-__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
-    f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
-    f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
-}
-
-// Contract exp: Cody-Waite + degree-6 Horner; only fma / mul / round-to-nearest-even.
-__device__ __forceinline__ float t3_expf(float x) {
-    if (!(x >= -87.0f)) return 0.0f;
-    if (x > 88.0f) x = 88.0f;
-    const float n = __builtin_rintf(x * 1.44269502162933349609375f);
-    float r = __builtin_fmaf(n, -0.693145751953125f, x);
-    r = __builtin_fmaf(n, -1.428606765330187045e-06f, r);
-    float p = 1.388888922519981861e-03f;
-    p = __builtin_fmaf(p, r, 8.333333767950534821e-03f);
-    p = __builtin_fmaf(p, r, 4.166666790843009949e-02f);
-    p = __builtin_fmaf(p, r, 1.666666716337203979e-01f);
-    p = __builtin_fmaf(p, r, 0.5f);
-    p = __builtin_fmaf(p, r, 1.0f);
-    p = __builtin_fmaf(p, r, 1.0f);
-    const int ni = (int)n;
-    const float s = __uint_as_float((uint32_t)(ni + 127) << 23);
-    return p * s;
-}
-
-__device__ __forceinline__ uint32_t silu_mul_bf(uint32_t g, uint32_t u) {   // bf16 bits in, bf16 bits out
-    const float gf = __uint_as_float(g << 16);
-    const float sg = rbf(gf / (1.0f + t3_expf(-gf)));
-    return f2bf(sg * __uint_as_float(u << 16));
-}
 
 // ------------------------------------------------------------------------------------------------
 // Skinny GEMM  y[m][n] = sum_k x[m][k] * W[n][k]   (x, W bf16, fp32 accumulation on the matrix cores)
@@ -92,23 +39,6 @@ __device__ __forceinline__ uint32_t silu_mul_bf(uint32_t g, uint32_t u) {   // b
 // register ring: vmcnt retires in issue order, so the activation loads must be issued as far ahead as the
 // weight loads or they would drain the weight prefetch every step.
 // ------------------------------------------------------------------------------------------------
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 ld_nt(const uint4* p) {      // streamed-once data: non-temporal load
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ bf16x8 as_frag(const uint4& v) {
-    union { uint4 u; bf16x8 f; } c; c.u = v; return c.f;
-}
-// two fp32 -> packed bf16 pair, round-to-nearest-even (v_cvt_pk_bf16_f32; equals f2bf() for every non-NaN input)
-__device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    union { bf2 v; uint32_t u; } c;
-    c.v = (bf2){(__bf16)lo, (__bf16)hi};
-    return c.u;
-}
-
 #ifdef T3_GEMM_CLK      // diagnostic build only (tools/gemm_clk.hip): per-workgroup phase stamps, 100 MHz ticks
 __device__ unsigned long long g_gemm_clk[8][2048][5];
 #define T3_GSTAMP(i) do { if (threadIdx.x == 0) g_gemm_clk[(EPI * 2 + (NW == 16)) & 7][(blockIdx.y * gridDim.x + blockIdx.x) & 2047][i] = wall_clock64(); } while (0)
@@ -1167,6 +1097,10 @@ __global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
         const unsigned long long uu = ((unsigned long long)rnd[1] << 32) | rnd[0];
         const unsigned long long target = __umul64hi(uu, Wk);
         int* tokp = reinterpret_cast<int*>(scr + 4);
+        // No thread owns the target when there is no mass at all (NaN logits: a checkpoint or conditioning with NaN / Inf makes
+        // every weight 0): the draw then falls back to the stop id instead of whatever the LDS word held.  The write is ordered
+        // before the owner's by the barriers inside block_scan_u64 above (scr + 4 is not one of its four words).
+        if (Wk == 0 && tid == 0) *tokp = (sp.stop_token >= 0 && sp.stop_token < V) ? sp.stop_token : 0;
         if (mine > 0 && target >= excl && target < excl + mine) {
             unsigned long long cum = excl; int found = -1;      // first entry whose running mass passes the target
 #pragma unroll
@@ -1178,6 +1112,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
         T3_CLK(9);
     }
     if (tid == 0) {
+        token = token < 0 ? 0 : (token >= V ? V - 1 : token);       // counts[] / speech_emb[] are indexed with it
         a.out_tok[u] = token;
         const uint16_t cnt = counts[token];
         if (cnt < 65535) counts[token] = cnt + 1;

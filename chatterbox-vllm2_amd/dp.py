@@ -44,3 +44,25 @@ def generate_sharded(generate_fn: Callable[[List[int]], List[List[int]]], n_item
             for i, toks in zip(idxs, outs):
                 results[i] = toks
     return mine, results
+
+
+def generate_data_parallel(llm, prompts: Sequence, sampling_params, rank: int, world: int, gather: bool = True):
+    """`LLM.generate` over a list of utterances sharded across `world` engine processes (one per GPU).
+
+    Every rank calls this with the SAME prompt list; each generates only its shard, with RNG streams keyed by the utterance's
+    global index (`uids`), and the token ids are exchanged once at the end (`all_gather_object`: ids only, a few hundred KB) --
+    nothing crosses GPUs while the engines step.  Returns a list aligned with `prompts` of offset-space token-id lists
+    (None for other ranks' utterances when gather=False).  The reference has no multi-GPU path; this is SURVEY.md 8(e)."""
+    sps = list(sampling_params) if isinstance(sampling_params, (list, tuple)) else [sampling_params] * len(prompts)
+
+    def cost(p, sp):
+        n_text = len(p["prompt_token_ids"]) if isinstance(p, dict) and "prompt_token_ids" in p else len(str(p.get("prompt", ""))) if isinstance(p, dict) else len(str(p))
+        return float(n_text + (sp.max_tokens or llm.max_model_len))
+
+    costs = [cost(p, sp) for p, sp in zip(prompts, sps)]
+
+    def run(idxs):
+        outs = llm.generate([prompts[i] for i in idxs], [sps[i] for i in idxs], uids=idxs)
+        return [o.outputs[0].token_ids for o in outs]
+
+    return generate_sharded(run, len(prompts), costs, rank, world, gather)[1]

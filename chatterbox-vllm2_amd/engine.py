@@ -60,8 +60,8 @@ class T3Stats(ct.Structure):
 # every symbol include/t3_engine.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
     "t3_create", "t3_destroy", "t3_last_error", "t3_load_tensor", "t3_finalize_weights", "t3_add_request",
-    "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_release_request",
-    "t3_clean_tokens", "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_kernel_ms",
+    "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_release_request", "t3_abort_request",
+    "t3_clean_tokens", "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_set_profile_kernel", "t3_kernel_ms",
     "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_sample", "t3k_expf",
     "t3_cond_create", "t3_cond_destroy", "t3_cond_last_error", "t3_cond_load_tensor", "t3_cond_encode", "t3_cond_emotion_row",
     "t3k_ce_layernorm", "t3k_ce_linear", "t3k_ce_attention", "t3k_set_prefill_rows",
@@ -103,11 +103,13 @@ def load_library():
     L.t3_num_unfinished.argtypes = [vp]
     L.t3_get_output.argtypes = [vp, i64, vp, ct.POINTER(i32), ct.POINTER(i32)]
     L.t3_release_request.argtypes = [vp, i64]
+    L.t3_abort_request.argtypes = [vp, i64]
     L.t3_clean_tokens.argtypes = [vp, i32, i32, i32, vp, ct.POINTER(i32)]
     L.t3_debug_logits.argtypes = [vp, i64, vp]
     L.t3_stats.argtypes = [vp, ct.POINTER(T3Stats)]
     L.t3_reset_stats.argtypes = [vp]
     L.t3_set_profile.argtypes = [vp, i32]
+    L.t3_set_profile_kernel.argtypes = [vp, ct.c_char_p]
     L.t3_kernel_ms.argtypes = [vp, ct.c_char_p, ct.POINTER(ct.c_double), ct.POINTER(i64)]
     L.t3k_gemm.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32]
     L.t3k_norm_gemm.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32]
@@ -240,6 +242,10 @@ class T3Engine:
     def release(self, req_id: int):
         self._chk(self.lib.t3_release_request(self.h, int(req_id)))
 
+    def abort(self, req_id: int):
+        """Drop a request in any state (a waiting one leaves the queue, a running one frees its slot and KV blocks)."""
+        self._chk(self.lib.t3_abort_request(self.h, int(req_id)))
+
     def debug_logits(self, req_id: int) -> torch.Tensor:
         out = torch.empty(C.SPEECH_VOCAB, dtype=torch.float32)
         self._chk(self.lib.t3_debug_logits(self.h, int(req_id), ct.c_void_p(out.data_ptr())))
@@ -254,7 +260,9 @@ class T3Engine:
     def reset_stats(self):
         self._chk(self.lib.t3_reset_stats(self.h))
 
-    def set_profile(self, on: bool):
+    def set_profile(self, on: bool, only: Optional[str] = None):
+        """HIP events around every kernel launch of decode-only steps; only = one kernel class (the rest runs undisturbed)."""
+        self._chk(self.lib.t3_set_profile_kernel(self.h, only.encode() if only else None))
         self._chk(self.lib.t3_set_profile(self.h, int(on)))
 
     def kernel_ms(self, name: str) -> Tuple[float, int]:

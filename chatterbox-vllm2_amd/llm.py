@@ -124,6 +124,7 @@ class LLM:
         tf = find_tokenizer_file(self.tokenizer_kind, model if model and os.path.isdir(model) else None, tokenizer_file)
         self.tokenizer = TextTokenizer(self.tokenizer_kind, tf) if tf else None
         self._next_id = 0
+        self._next_uid = 0            # RNG stream of the next unseeded request (see generate)
 
     # -- vLLM API -------------------------------------------------------------------------------
     def get_tokenizer(self):
@@ -145,7 +146,14 @@ class LLM:
         return p["prompt"], self.tokenizer.encode(p["prompt"]), cond
 
     def generate(self, prompts: Union[PromptType, Sequence[PromptType]], sampling_params: Optional[Union[SamplingParams, Sequence[SamplingParams]]] = None,
-                 use_tqdm: bool = False, uid_base: int = 0) -> List[RequestOutput]:
+                 use_tqdm: bool = False, uid_base: Optional[int] = None, uids: Optional[Sequence[int]] = None) -> List[RequestOutput]:
+        """Randomness (the sampler draws from Philox keyed by (seed, uid, step), include/t3_engine.h):
+          * no SamplingParams.seed (what tts.py:455-464 does): every request takes the next RNG stream of this LLM object, so the
+            same text submitted twice gives two different utterances, while a fresh process replays the same sequence -- vLLM's
+            behaviour with its global `seed=0` default;
+          * SamplingParams.seed given: that request is reproducible wherever it sits (vLLM's per-request generator);
+          * uids (one per prompt) or uid_base (request i uses uid_base + i) given -- the data-parallel launcher, dp.py: the stream
+            is the utterance's GLOBAL index, so a sharded run emits the ids of the one-GPU run."""
         if isinstance(prompts, (str, dict)):
             prompts = [prompts]
         if sampling_params is None:
@@ -153,30 +161,29 @@ class LLM:
         sps = list(sampling_params) if isinstance(sampling_params, (list, tuple)) else [sampling_params] * len(prompts)
         if len(sps) != len(prompts):
             raise ValueError("The lengths of prompts and sampling_params must be the same.")
-        ids0 = self._next_id
+        if uids is not None and len(uids) != len(prompts):
+            raise ValueError("The lengths of prompts and uids must be the same.")
+        if uids is None and uid_base is not None:
+            uids = [int(uid_base) + i for i in range(len(prompts))]
         metas = []
-        for i, (p, sp) in enumerate(zip(prompts, sps)):
-            text, tids, cond = self._text_ids(p)
-            final = assemble_prompt_ids(tids)
-            stop = -1
-            if sp.stop_token_ids:
-                if len(sp.stop_token_ids) > 1:
-                    raise ValueError("the T3 engine supports one stop token id")
-                stop = int(sp.stop_token_ids[0]) - C.SPEECH_TOKEN_OFFSET          # 9062 -> 6562 (tts.py:458)
-            max_tokens = sp.max_tokens if sp.max_tokens is not None else self.max_model_len
-            esp = make_sampling(temperature=sp.temperature, top_p=sp.top_p, min_p=sp.min_p, repetition_penalty=sp.repetition_penalty,
-                                presence_penalty=sp.presence_penalty, frequency_penalty=sp.frequency_penalty,
-                                top_k=max(0, sp.top_k), max_tokens=max_tokens, ignore_eos=sp.ignore_eos, stop_token=stop,
-                                seed=self.seed if sp.seed is None else sp.seed, uid=uid_base + i, pos_policy=sp.pos_policy)
-            rid = self._next_id; self._next_id += 1
-            try:
-                self.engine.add_request(rid, final, cond, esp)
-            except Exception:
-                for r in range(ids0, rid):     # roll back what this call queued: nothing has run yet
+        queued: List[int] = []
+        uid0 = self._next_uid
+        try:
+            self._queue(prompts, sps, uids, metas, queued)
+        except Exception:
+            for rid in queued:             # nothing of this call has run yet: leave the engine as it was found
+                self.engine.abort(rid)
+            self._next_uid = uid0
+            raise
+        try:
+            self.engine.run_until_done()
+        except Exception:
+            for rid in queued:             # e.g. a request that can never be admitted (KV pool too small): drop the whole call
+                try:
+                    self.engine.abort(rid)
+                except Exception:
                     pass
-                raise
-            metas.append((rid, text, final))
-        self.engine.run_until_done()
+            raise
         outs = []
         for rid, text, final in metas:
             toks, fr = self.engine.get_output(rid)
@@ -186,6 +193,31 @@ class LLM:
                                       outputs=[CompletionOutput(index=0, text="", token_ids=toks, finish_reason=reason,
                                                                 stop_reason=(toks[-1] if fr == 1 else None))]))
         return outs
+
+    def _queue(self, prompts, sps, uids, metas, queued):
+        for i, (p, sp) in enumerate(zip(prompts, sps)):
+            text, tids, cond = self._text_ids(p)
+            final = assemble_prompt_ids(tids)
+            stop = -1
+            if sp.stop_token_ids:
+                if len(sp.stop_token_ids) > 1:
+                    raise ValueError("the T3 engine supports one stop token id")
+                stop = int(sp.stop_token_ids[0]) - C.SPEECH_TOKEN_OFFSET          # 9062 -> 6562 (tts.py:458)
+            max_tokens = sp.max_tokens if sp.max_tokens is not None else self.max_model_len
+            if uids is not None:
+                uid = int(uids[i])
+            elif sp.seed is not None:
+                uid = 0
+            else:
+                uid = self._next_uid; self._next_uid += 1
+            esp = make_sampling(temperature=sp.temperature, top_p=sp.top_p, min_p=sp.min_p, repetition_penalty=sp.repetition_penalty,
+                                presence_penalty=sp.presence_penalty, frequency_penalty=sp.frequency_penalty,
+                                top_k=max(0, sp.top_k), max_tokens=max_tokens, ignore_eos=sp.ignore_eos, stop_token=stop,
+                                seed=self.seed if sp.seed is None else sp.seed, uid=uid, pos_policy=sp.pos_policy)
+            rid = self._next_id; self._next_id += 1
+            self.engine.add_request(rid, final, cond, esp)
+            queued.append(rid)
+            metas.append((rid, text, final))
 
     def shutdown(self):
         self.engine.close()

@@ -101,12 +101,15 @@ def _korean_normalize(text: str) -> str:
 class TextTokenizer:
     """kind = "EnTokenizer" | "MtlTokenizer" (the names the reference registers, t3/__init__.py:6-7)."""
 
-    def __init__(self, kind: str, path: str):
+    def __init__(self, kind: str, path: str, strict: bool = True):
+        """strict: refuse the four languages whose reference normaliser cannot run here (zh / ja / he / ru) instead of
+        emitting un-normalised ids; strict=False is for fixtures that want the raw ids (tests/golden/make_golden.py g9)."""
         from tokenizers import Tokenizer
 
         if kind not in _FILES:
             raise ValueError(f"unknown tokenizer {kind!r}")
         self.kind = kind
+        self.strict = strict
         self.tok = Tokenizer.from_file(path)
 
     @property
@@ -126,8 +129,9 @@ class TextTokenizer:
         elif language_id in ("zh", "ja", "he", "ru"):
             # the reference runs Cangjie / kakasi / dicta / a stress marker here (mtltokenizer.py:311-320); those need
             # packages or a download that this image does not have, so these four languages are not pinned.
-            import warnings
-            warnings.warn(f"language-specific normaliser for {language_id!r} is not applied")
+            if self.strict:
+                raise ValueError(f"language {language_id!r} needs a text normaliser (mtltokenizer.py:311-320) that is not available in this "
+                                 "build: its ids would differ from the reference's; pass prompt_token_ids instead")
         if language_id:
             text = f"[{language_id.lower()}]{text}"
         return self.tok.encode(text.replace(" ", SPACE)).ids

@@ -126,6 +126,11 @@ int t3_num_unfinished(T3Handle h);
  * On entry *n = capacity; on exit *n = number of tokens.  finish_reason: 0 running, 1 stop, 2 length. */
 int t3_get_output(T3Handle h, int64_t req_id, int32_t* ids, int32_t* n, int32_t* finish_reason);
 int t3_release_request(T3Handle h, int64_t req_id);   /* forget a finished request */
+/* Drop a request in any state -- vLLM's abort_request: a WAITING one leaves the queue, a running one gives its slot and KV
+ * blocks back -- and forget it.  The host mirror uses it to roll back a generate() call whose later prompt was rejected
+ * (api_server.py:323-326 turns that ValueError into HTTP 400 and the engine must be left empty).  Not valid while a step is
+ * in flight (the engine is single-threaded: call it between t3_step / t3_run_* calls). */
+int t3_abort_request(T3Handle h, int64_t req_id);
 
 /* ---- token post-filter: ChatterboxTTS.analyze_and_clean_tokens (tts.py:300-365) driving the fork's
  * token-heuristic AlignmentStreamAnalyzer.step (models/t3/inference/alignment_stream_analyzer.py:111-201), plus the
@@ -148,6 +153,9 @@ int t3_reset_stats(T3Handle h);
  * measured with HIP events on the engine's stream when profiling is on (t3_set_profile).
  * names: "gemm_qkv","gemm_o","gemm_gateup","gemm_down","gemm_head","attention","rope_kv","embed","sampler". */
 int t3_set_profile(T3Handle h, int32_t on);
+/* Restrict the events to ONE kernel class (name as above; NULL or "" = every class): the other launches of the step then run
+ * undisturbed, so the class's average duration is not inflated by its neighbours' event packets. */
+int t3_set_profile_kernel(T3Handle h, const char* name);
 int t3_kernel_ms(T3Handle h, const char* name, double* avg_ms, int64_t* launches);
 
 /* ---- conditioning encoder --------------------------------------------------

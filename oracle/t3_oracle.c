@@ -629,6 +629,7 @@ int orc_sample(const float* logits_in, const uint16_t* counts /* [8194] generate
         }
     }
     uint64_t Wk = 0; for (int v = 0; v < T3_V; ++v) if (keep[v]) Wk += w[v];
+    if (Wk == 0) return (sp->stop_token >= 0 && sp->stop_token < T3_V) ? sp->stop_token : 0;   /* no mass at all (NaN logits): end the utterance */
     uint32_t rnd[4];
     orc_philox(step, (uint32_t)sp->uid, (uint32_t)(sp->uid >> 32), 0, (uint32_t)sp->seed, (uint32_t)(sp->seed >> 32), rnd);
     const uint64_t u = ((uint64_t)rnd[1] << 32) | rnd[0];

@@ -15,6 +15,8 @@ What comes from where:
   G8  postfilter.json  -- decisions of the reference's AlignmentStreamAnalyzer (imported, CPU) over random / planted token lists
   G7  tokenizer.json   -- token ids of the fixed en/es utterances from the reference's
                           tokenizer JSON files via the `tokenizers` library.
+  G9  c4_requests.json -- token ids of the sentences of the reference's docs/benchmark-text-*.txt (C4 request stream)
+  G6b streams30.npz    -- 30-layer oracle streams for C3 uids 0 / 17 and six C4 requests (multilingual vocabulary)
 No reference source text is stored: only inputs and numeric outputs.
 """
 import json
@@ -195,6 +197,61 @@ def g6_streams():
     print("G6 streams:", {k: v.shape for k, v in out.items()})
 
 
+def g9_c4_requests():
+    """C4 request stream (BASELINE.json configs[3]): sentences of the reference's docs/benchmark-text-{1,2,fr-1,zh-1}.txt,
+    split on sentence enders, cleaned with punc_norm, decorated as tts.py:435-441 does and tokenised HERE with the f2 tokenizer over the
+    reference's multilingual vocabulary file (zh: raw ids, the Cangjie table is an un-fetchable download).  Only token ids are stored, plus a
+    per-request output length G ~ U{200..800} (seed 7) capped so that T + G <= max_model_len = 1000."""
+    import re
+    from chatterbox_vllm2_amd.prompt import TextTokenizer, assemble_prompt_ids, punc_norm
+    mtl = TextTokenizer("MtlTokenizer", os.path.join(REF_PKG, "models/t3/grapheme_mtl_merged_expanded_v1.json"), strict=False)
+    rs = np.random.RandomState(7)
+    reqs = []
+    for fname, lang in (("1", "en"), ("2", "en"), ("fr-1", "fr"), ("zh-1", "zh")):
+        raw = open(os.path.join(REF, "docs", f"benchmark-text-{fname}.txt"), encoding="utf-8").read()
+        body = " ".join(l for l in raw.splitlines() if not l.startswith("#"))
+        sents = [x.strip() for x in re.split(r"(?<=[.!?\u3002\uff01\uff1f])\s*", body) if len(x.strip()) >= 2]
+        for k, sent in enumerate(sents):
+            ids = mtl.encode(f"<{lang}>[START]{punc_norm(sent)}[STOP]")
+            T = len(assemble_prompt_ids(ids))
+            g = int(rs.randint(200, 801))
+            reqs.append({"src": f"{fname}:{k}", "lang": lang, "text_ids": [int(i) for i in ids], "max_tokens": min(g, 1000 - T - 1)})
+    out = {"max_model_len": 1000, "slots": 128, "seed_G": 7, "sampling": {"temperature": 0.8, "top_p": 0.8, "repetition_penalty": 2.0, "seed": 0},
+           "uid": "request index", "requests": reqs}
+    json.dump(out, open(os.path.join(HERE, "c4_requests.json"), "w"), separators=(",", ":"))
+    print("G9 c4 requests:", len(reqs), "total output tokens", sum(r["max_tokens"] for r in reqs),
+          "text ids min/mean/max", min(len(r["text_ids"]) for r in reqs), sum(len(r["text_ids"]) for r in reqs) // len(reqs), max(len(r["text_ids"]) for r in reqs))
+
+
+C4_GOLDEN_REQUESTS = (0, 3, 250, 431, 464, 480)     # en (long), en, en (text 2), fr, zh, zh
+
+
+def g6b_streams_30_layers_multilingual():
+    """30-layer oracle streams at the production batch shapes' inputs: C3 uids 0 (en) and 17 (es), and six C4 requests --
+    what the 64-row / 256-row GEMM schedules and the continuous-batching loop must reproduce on the device."""
+    from oracle import oracle as O
+    from chatterbox_vllm2_amd.prompt import assemble_prompt_ids
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb, synthetic_tensors
+    tok = json.load(open(os.path.join(HERE, "tokenizer.json")))
+    c4 = json.load(open(os.path.join(HERE, "c4_requests.json")))
+    cond = synthetic_cond_emb(1)
+    m = O.OracleModel(30, 2454, max_pos=400).load(synthetic_tensors(30, 2454, 1234))
+    out = {}
+    kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, ignore_eos=True)
+    for uid, key in ((0, "en_mtl_ids"), (17, "es_mtl_ids")):
+        ids, lg = m.generate(assemble_prompt_ids(tok[key]), cond, O.make_sampling(uid=uid, max_tokens=24, **kw), want_logits=True, max_model_len=400)
+        out[f"c3_uid{uid}_ids"] = np.array(ids, np.int32); out[f"c3_uid{uid}_logits_step0"] = lg[0].numpy()
+        print("  c3 uid", uid, ids[:8], flush=True)
+    for i in C4_GOLDEN_REQUESTS:
+        r = c4["requests"][i]
+        ids, _ = m.generate(assemble_prompt_ids(r["text_ids"]), cond, O.make_sampling(uid=i, max_tokens=32, **kw), max_model_len=400)
+        out[f"c4_req{i}_ids"] = np.array(ids, np.int32)
+        print("  c4 req", i, r["lang"], len(r["text_ids"]), ids[:8], flush=True)
+    m.close()
+    np.savez_compressed(os.path.join(HERE, "streams30.npz"), **out)
+    print("G6b streams30:", {k: v.shape for k, v in out.items()})
+
+
 def g8_postfilter():
     """Decisions of the reference's AlignmentStreamAnalyzer (imported; run on CPU) driven by the loop of tts.py:329-350."""
     import importlib
@@ -232,7 +289,7 @@ def g8_postfilter():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1b", "g3", "g7", "g7b", "g6", "g8"]
+    which = sys.argv[1:] or ["g1", "g1b", "g3", "g7", "g7b", "g6", "g8", "g9", "g6b"]
     if "g1" in which: g1_cond_enc()
     if "g1b" in which: g1b_cond_enc_synthetic()
     if "g3" in which: g3_rope()
@@ -240,3 +297,5 @@ if __name__ == "__main__":
     if "g7b" in which: g7b_tokenizer_cases()
     if "g6" in which: g6_streams()
     if "g8" in which: g8_postfilter()
+    if "g9" in which: g9_c4_requests()
+    if "g6b" in which: g6b_streams_30_layers_multilingual()

@@ -234,23 +234,163 @@ def test_error_behaviour(E, tiny_engine, cond):
     assert tiny_engine.num_unfinished() == 0
 
 
-def test_llm_surface(E, cond):
-    """The vLLM-shaped API used at tts.py:445-492."""
+def _toy_tokenizer_file(path):
+    """A small character-level `tokenizers` file with the special tokens the English path relies on (ids 255 / 0 / 2 as in the
+    reference's vocabulary); the reference's own tokenizer.json does not travel to the GPU box."""
+    from tokenizers import Regex, Tokenizer, models, pre_tokenizers
+    vocab = {f"[FILL{i}]": i for i in range(256)}
+    vocab.pop("[FILL0]"); vocab.pop("[FILL1]"); vocab.pop("[FILL2]"); vocab.pop("[FILL255]")
+    vocab.update({"[STOP]": 0, "[UNK]": 1, "[SPACE]": 2, "[START]": 255})
+    for k, ch in enumerate("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ.,!?'-"):
+        vocab.pop(f"[FILL{10 + k}]"); vocab[ch] = 10 + k
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="[UNK]"))
+    tok.add_special_tokens(["[START]", "[STOP]", "[SPACE]", "[UNK]"])
+    tok.pre_tokenizer = pre_tokenizers.Split(Regex("."), "isolated")
+    tok.save(str(path))
+    return str(path)
+
+
+def test_llm_surface(E, oracle, tiny_oracle, cond, tmp_path):
+    """The vLLM-shaped API used at tts.py:445-492, checked against the oracle and the committed goldens."""
+    import json, os
     from chatterbox_vllm2_amd import LLM, SamplingParams
+    from chatterbox_vllm2_amd.prompt import assemble_prompt_ids
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(G, "streams.npz")); tokj = json.load(open(os.path.join(G, "tokenizer.json")))
     llm = LLM(model="./t3-model", task="generate", tokenizer="EnTokenizer", tokenizer_mode="custom", gpu_memory_utilization=0.2,
-              enforce_eager=True, max_model_len=200, max_num_seqs=4, load_format="dummy", num_hidden_layers=2)
-    text = make_prompt(10, seed=3)[34:-1]
-    res = llm.generate([{"prompt_token_ids": text, "multi_modal_data": {"conditionals": [cond]}}] * 3,
-                       sampling_params=SamplingParams(temperature=0.8, stop_token_ids=[6562 + 2500], max_tokens=min(1000, 200), top_p=0.8, repetition_penalty=2.0))
+              enforce_eager=True, max_model_len=400, max_num_seqs=4, load_format="dummy", num_hidden_layers=2,
+              tokenizer_file=_toy_tokenizer_file(tmp_path / "toy_tokenizer.json"))
+    mm = {"conditionals": [cond]}
+    # (1) committed goldens (C1 prompt, 2 layers): greedy, and the reference's sampling defaults with an explicit seed
+    c1 = {"prompt_token_ids": tokj["en_english_ids"], "multi_modal_data": mm}
+    r = llm.generate([c1], SamplingParams(temperature=0.0, max_tokens=64, ignore_eos=True))
+    assert [t - 2500 for t in r[0].outputs[0].token_ids] == z["l2_en_greedy_ids"].tolist()
+    sp_seeded = SamplingParams(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, max_tokens=64, ignore_eos=True)
+    r = llm.generate([c1], sp_seeded)
+    assert [t - 2500 for t in r[0].outputs[0].token_ids] == z["l2_en_sampled_ids"].tolist()
+    assert llm.generate([c1, c1], sp_seeded)[1].outputs[0].token_ids == r[0].outputs[0].token_ids      # per-request seed: position-independent
+    # (2) a prompt STRING through the tokenizer front-end, against the oracle on the same ids (tts.py:435: "[START]" + text + "[STOP]")
+    text = "[START]Hello there, world![STOP]"
+    ids = llm.get_tokenizer().encode(text)
+    assert ids[0] == 255 and ids[-1] == 0 and ids.count(2) == 2
+    sp = SamplingParams(temperature=0.8, stop_token_ids=[6562 + 2500], max_tokens=min(1000, 400), top_p=0.8, repetition_penalty=2.0)   # tts.py:455-464
+    u0 = llm._next_uid                                        # unseeded requests take consecutive RNG streams
+    res = llm.generate([{"prompt": text, "multi_modal_data": mm}] * 3, sampling_params=sp)
     assert len(res) == 3
-    for r in res:
-        for o in r.outputs:
-            assert len(o.token_ids) > 0 and min(o.token_ids) >= 2500
-            assert o.finish_reason in ("stop", "length")
-    # same prompt, different uid -> different streams; same uid -> same stream
-    again = llm.generate([{"prompt_token_ids": text, "multi_modal_data": {"conditionals": [cond]}}],
-                         sampling_params=SamplingParams(temperature=0.8, stop_token_ids=[9062], max_tokens=200, top_p=0.8, repetition_penalty=2.0))
-    assert again[0].outputs[0].token_ids == res[0].outputs[0].token_ids
-    with pytest.raises(ValueError):
-        llm.generate(["plain string"], SamplingParams())
+    for k, r in enumerate(res):
+        want, _ = tiny_oracle.generate(assemble_prompt_ids(ids), cond, oracle.make_sampling(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, uid=u0 + k,
+                                                                                          max_tokens=400), max_model_len=400)
+        o = r.outputs[0]
+        assert [t - 2500 for t in o.token_ids] == want and min(o.token_ids) >= 2500
+        assert o.finish_reason == ("stop" if want[-1] == 6562 else "length")
+    # unseeded requests take fresh RNG streams: the same text again is a different utterance (the reference sets no seed)
+    again = llm.generate([{"prompt": text, "multi_modal_data": mm}], sampling_params=sp)
+    assert all(again[0].outputs[0].token_ids != r.outputs[0].token_ids for r in res)
+    # (3) a bad prompt in the middle of a list: ValueError (HTTP 400, api_server.py:323-326) and NOTHING stays queued
+    good = {"prompt": text, "multi_modal_data": mm}
+    for bad in ({"prompt_token_ids": [255, 9999, 0], "multi_modal_data": mm}, {"prompt": text, "multi_modal_data": {"conditionals": [cond[:10]]}}, "plain string"):
+        with pytest.raises(ValueError):
+            llm.generate([good, good, bad, good], sp)
+        assert llm.engine.num_unfinished() == 0
+    st = llm.engine.stats()
+    assert st.kv_blocks_free == st.kv_blocks_total
+    nxt = llm.generate([good], SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True))       # the engine is still usable and empty
+    assert len(nxt[0].outputs[0].token_ids) == 8
     llm.shutdown()
+
+
+def test_abort_request_states(E, tiny_engine, cond):
+    """t3_abort_request: a waiting request leaves the queue, a running one frees its slot and blocks, unknown ids are reported."""
+    sp = E.make_sampling(temperature=0.0, max_tokens=50, ignore_eos=True)
+    free0 = tiny_engine.stats().kv_blocks_free
+    for rid in (900, 901, 902):
+        tiny_engine.add_request(rid, make_prompt(10, seed=rid), cond, sp)
+    tiny_engine.abort(901)                                   # still waiting
+    tiny_engine.step(); tiny_engine.step()                   # 900 and 902 are decoding now
+    assert tiny_engine.num_unfinished() == 2 and tiny_engine.stats().kv_blocks_free < free0
+    tiny_engine.abort(900)
+    assert tiny_engine.num_unfinished() == 1
+    tiny_engine.run_until_done()
+    assert len(tiny_engine.get_output(902)[0]) == 50
+    tiny_engine.release(902)
+    assert tiny_engine.stats().kv_blocks_free == free0
+    with pytest.raises(E.T3Error):
+        tiny_engine.abort(900)                               # already gone
+
+
+def test_non_finite_conditioning_is_rejected(E, tiny_engine, cond):
+    bad = cond.clone(); bad[3, 7] = float("nan")
+    with pytest.raises(ValueError):
+        tiny_engine.add_request(950, make_prompt(10, seed=1), bad, E.make_sampling())
+    bad[3, 7] = float("inf")
+    with pytest.raises(ValueError):
+        tiny_engine.add_request(950, make_prompt(10, seed=1), bad, E.make_sampling())
+    assert tiny_engine.num_unfinished() == 0
+
+
+def test_real_checkpoint_path_safetensors(E, cond, tmp_path):
+    """`LLM(model=<dir>)` -> weights.iter_safetensors -> t3_load_tensor name routing (t3.py:300-332), with the extra tensors a real
+    checkpoint carries (cond_enc.*, text_head.*, tfmr.embed_tokens.*) skipped like t3.py:316-319; ids equal the committed goldens."""
+    import json, os
+    from safetensors.torch import save_file
+    from chatterbox_vllm2_amd import LLM, SamplingParams
+    from chatterbox_vllm2_amd.weights import synthetic_cond_enc_tensors, synthetic_tensors
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(G, "streams.npz")); tokj = json.load(open(os.path.join(G, "tokenizer.json")))
+    sd = {k: v.contiguous() for k, v in synthetic_tensors(2, 704, 1234)}
+    sd.update({k: v for k, v in synthetic_cond_enc_tensors(4321)})
+    sd["text_head.weight"] = torch.zeros(704, 1024, dtype=torch.bfloat16)
+    sd["tfmr.embed_tokens.weight"] = torch.zeros(8, 1024, dtype=torch.bfloat16)
+    mdir = tmp_path / "t3-model"; mdir.mkdir()
+    save_file(sd, str(mdir / "model.safetensors"))
+    llm = LLM(model=str(mdir), task="generate", tokenizer="EnTokenizer", tokenizer_mode="custom", gpu_memory_utilization=0.2,
+              enforce_eager=True, max_model_len=400, max_num_seqs=2, num_hidden_layers=2)
+    r = llm.generate([{"prompt_token_ids": tokj["en_english_ids"], "multi_modal_data": {"conditionals": [cond]}}],
+                     SamplingParams(temperature=0.0, max_tokens=64, ignore_eos=True))
+    assert [t - 2500 for t in r[0].outputs[0].token_ids] == z["l2_en_greedy_ids"].tolist()
+    llm.shutdown()
+    with pytest.raises(ValueError):
+        LLM(model=str(tmp_path / "nowhere"), tokenizer="EnTokenizer", num_hidden_layers=2)        # no checkpoint, no load_format="dummy"
+
+
+_DP_GPU_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+from chatterbox_vllm2_amd import LLM, SamplingParams
+from chatterbox_vllm2_amd.dp import generate_data_parallel
+from chatterbox_vllm2_amd.weights import synthetic_cond_emb
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from util import make_prompt
+cond = synthetic_cond_emb(1)
+llm = LLM(model="", tokenizer="EnTokenizer", load_format="dummy", num_hidden_layers=2, max_model_len=200, max_num_seqs=4, kv_cache_bytes=1 << 28,
+          enforce_eager=False, device_id=0)
+prompts = [{"prompt_token_ids": make_prompt(6 + 3 * i, seed=40 + i)[34:-1], "multi_modal_data": {"conditionals": [cond]}} for i in range(7)]
+sps = [SamplingParams(temperature=0.8, top_p=0.8, repetition_penalty=2.0, max_tokens=12 + 5 * (i % 3), ignore_eos=True) for i in range(7)]
+res = generate_data_parallel(llm, prompts, sps, rank, world)
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+print("RESULT " + json.dumps(res))
+llm.shutdown()
+'''
+
+
+def test_data_parallel_llm_world2_equals_world1(tmp_path):
+    """SURVEY.md 8(e): the utterance list sharded over two engine processes (gloo between them, both on this box's one GPU) emits
+    exactly the ids of the one-process run -- RNG streams are keyed by the global utterance index, nothing crosses ranks in a step."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dpw.py"; script.write_text(_DP_GPU_WORKER)
+    def run(world, port):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+        outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        return [json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][-1][7:]) for o in outs]
+    one = run(1, 29571)[0]
+    two = run(2, 29572)
+    assert two[0] == one and two[1] == one
+    assert len(one) == 7 and all(len(t) == 12 + 5 * (i % 3) for i, t in enumerate(one))

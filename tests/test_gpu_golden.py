@@ -72,8 +72,9 @@ def test_c2_full_depth_30_layers(ctx):
 
 
 def test_full_size_batch_invariance_c3(ctx):
-    """BASELINE size (30 layers, B = 32, max_model_len 1000): an utterance's stream does not depend on its batch
-    (size-independent property; 24 tokens).  Also exercises hipGraph replay at full size."""
+    """BASELINE size (30 layers, B = 32, max_model_len 1000, graph replay): utterances 0 (en) and 17 (es) of the batch against their
+    committed 30-layer ORACLE streams (streams30.npz) -- the 64-row production GEMM schedules at full depth -- and an utterance's
+    stream does not depend on its batch (B = 32 vs B = 1)."""
     E = ctx["E"]
     en, es = ctx["asm"](ctx["tok"]["en_mtl_ids"]), ctx["asm"](ctx["tok"]["es_mtl_ids"])
     eng = E.T3Engine(n_layers=30, text_vocab=2454, max_model_len=1000, max_seqs=32, kv_bytes=10 << 30, enforce_eager=False, max_batched_rows=8192)
@@ -83,6 +84,9 @@ def test_full_size_batch_invariance_c3(ctx):
         eng.add_request(i, en if i < 16 else es, ctx["cond"], E.make_sampling(uid=i, **kw))
     eng.run_until_done()
     batch = {i: eng.get_output(i)[0] for i in range(32)}
+    z30 = np.load(os.path.join(G, "streams30.npz"))
+    for i in (0, 17):
+        assert [t - 2500 for t in batch[i]] == z30[f"c3_uid{i}_ids"].tolist(), f"utterance {i} of the B=32 batch differs from the 30-layer oracle stream"
     for i in range(32):
         eng.release(i)
     for i in (0, 17, 31):
@@ -91,4 +95,37 @@ def test_full_size_batch_invariance_c3(ctx):
         assert eng.get_output(100 + i)[0] == batch[i], f"utterance {i} differs between B=32 and B=1"
         eng.release(100 + i)
     assert len({tuple(v) for v in batch.values()}) == 32        # distinct uids -> distinct streams
+    eng.close()
+
+
+def test_c4_continuous_batching_full_size(ctx):
+    """C4 (BASELINE.json configs[3]): the request stream tokenised from the reference's docs/benchmark-text-*.txt (c4_requests.json: 499
+    sentences, en / fr / zh, G ~ U{200..800}) through 128 slots x 30 layers with graph replay and the run-ahead loop -- admission, chunked
+    prefill between decode steps (the 256-row decode schedules), retirement.  Six utterances against their committed 30-layer oracle
+    streams (first 32 tokens: streams are batch-invariant), every utterance runs to its length, every KV block comes back."""
+    E = ctx["E"]
+    c4 = json.load(open(os.path.join(G, "c4_requests.json")))
+    z30 = np.load(os.path.join(G, "streams30.npz"))
+    reqs = c4["requests"]
+    eng = E.T3Engine(n_layers=30, text_vocab=2454, max_model_len=c4["max_model_len"], max_seqs=c4["slots"], gpu_memory_utilization=0.5,
+                     enforce_eager=False, max_batched_rows=8192)
+    eng.load_tensors(ctx["syn"](30, 2454, 1234)); eng.finalize()
+    total_blocks = eng.stats().kv_blocks_total
+    for i, r in enumerate(reqs):
+        eng.add_request(i, ctx["asm"](r["text_ids"]), ctx["cond"], E.make_sampling(uid=i, max_tokens=r["max_tokens"], ignore_eos=True, **c4["sampling"]))
+    eng.run_until_done()
+    st = eng.stats()
+    assert st.tokens_generated == sum(r["max_tokens"] for r in reqs)
+    assert st.kv_blocks_free == total_blocks == st.kv_blocks_total
+    checked = 0
+    for i, r in enumerate(reqs):
+        ids, fr = eng.get_output(i)
+        assert len(ids) == r["max_tokens"] and fr == 2
+        key = f"c4_req{i}_ids"
+        if key in z30.files:
+            want = z30[key].tolist()
+            assert [t - 2500 for t in ids[:len(want)]] == want, f"C4 request {i} ({r['lang']}) differs from the 30-layer oracle stream"
+            checked += 1
+        eng.release(i)
+    assert checked == 6
     eng.close()

@@ -133,3 +133,66 @@ def test_data_parallel_sharding_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_strict_tokenizer_refuses_unpinned_languages(tmp_path):
+    """zh / ja / he / ru need normalisers (mtltokenizer.py:311-320) that cannot run here: refuse rather than emit other ids."""
+    ref = "/root/reference/src/chatterbox_vllm/models/t3/grapheme_mtl_merged_expanded_v1.json"
+    if not os.path.exists(ref):
+        pytest.skip("reference vocabulary file not present on this box")
+    from chatterbox_vllm2_amd.prompt import TextTokenizer
+    strict, loose = TextTokenizer("MtlTokenizer", ref), TextTokenizer("MtlTokenizer", ref, strict=False)
+    for lang in ("zh", "ja", "he", "ru"):
+        with pytest.raises(ValueError):
+            strict.encode(f"<{lang}>[START]x[STOP]")
+        assert len(loose.encode(f"<{lang}>[START]x[STOP]")) > 3
+    assert strict.encode("<fr>[START]oui[STOP]") == loose.encode("<fr>[START]oui[STOP]")
+
+
+def test_c4_fixture_shape():
+    c4 = json.load(open(os.path.join(G, "c4_requests.json")))
+    reqs = c4["requests"]
+    assert len(reqs) == 499 and {r["lang"] for r in reqs} == {"en", "fr", "zh"}
+    for r in reqs:
+        T = 34 + len(r["text_ids"]) + 1
+        assert 200 <= r["max_tokens"] <= 800 and T + r["max_tokens"] <= c4["max_model_len"] - 1 + 1
+        assert all(0 <= t < 2454 for t in r["text_ids"])
+
+
+def test_safetensors_iterator_yields_checkpoint_names(tmp_path):
+    """weights.iter_safetensors: the real-checkpoint entry (tts.py:225-229 symlinks it to <model dir>/model.safetensors)."""
+    from safetensors.torch import save_file
+    from chatterbox_vllm2_amd.weights import iter_safetensors, synthetic_tensors
+    sd = {k: v.contiguous() for k, v in synthetic_tensors(1, 704, 1234)}
+    sd["text_head.weight"] = torch.zeros(704, 1024)              # fp32 extras are cast on the way in
+    d = tmp_path / "m"; d.mkdir(); save_file(sd, str(d / "model.safetensors"))
+    got = dict(iter_safetensors(str(d)))
+    assert set(got) == set(sd) and all(t.dtype == torch.bfloat16 for t in got.values())
+    assert torch.equal(got["tfmr.layers.0.mlp.down_proj.weight"], sd["tfmr.layers.0.mlp.down_proj.weight"])
+
+
+def test_bench_window_is_centred_and_self_launching(monkeypatch, capsys):
+    """bench.py: the timed window sits on the run midpoint whatever --steps is, and `--gpus N` without a launcher starts the ranks."""
+    import importlib, types
+    bench = importlib.import_module("bench")
+    centres = []
+    for steps, warmup in ((20, 5), (800, 20), (200, 0), (1, 0)):
+        a = types.SimpleNamespace(steps=steps, warmup=warmup, max_model_len=1000, batch=32, layers=30)
+        ff, first, last = bench.plan_window(a)
+        assert ff >= 0 and last <= 1000 - 141 - 3 + 1
+        centres.append((first + last - 1) / 2)
+    assert max(centres) - min(centres) <= 2.0 and abs(centres[0] - 430) <= 2.0          # C3 mean context 128.5 + ~430
+    assert "C3" in bench.workload_string(types.SimpleNamespace(steps=20, warmup=5, max_model_len=1000, batch=32, layers=30), 1, 2)
+    assert "custom" in bench.workload_string(types.SimpleNamespace(steps=20, warmup=5, max_model_len=400, batch=1, layers=30), 1, 2)
+    seen = {}
+    def fake_run(cmd, **kw):
+        seen["cmd"] = cmd
+        return types.SimpleNamespace(returncode=0, stdout='noise\n{"metric": "m", "value": 1}\n')
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    with pytest.raises(SystemExit) as ex:
+        bench.spawn_ranks(types.SimpleNamespace(gpus=4))
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd and cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    assert capsys.readouterr().out.strip() == '{"metric": "m", "value": 1}'
