@@ -34,8 +34,8 @@ static thread_local std::string g_create_error;
 namespace {
 
 struct LayerW {
-    uint16_t *qkv = nullptr, *o = nullptr, *gu = nullptr, *down = nullptr, *ln1 = nullptr, *ln2 = nullptr;  // device, packed
-    std::vector<uint16_t> h_q, h_k, h_v, h_g, h_u;   // host staging until finalize
+    uint16_t *qkv = nullptr, *o = nullptr, *gu = nullptr, *down = nullptr;  // device, packed (qkv / gu carry their RMSNorm weight, fold_norm_weight)
+    std::vector<uint16_t> h_q, h_k, h_v, h_g, h_u, h_ln1, h_ln2;   // host staging until finalize
     bool have_o = false, have_d = false;
 };
 
@@ -77,7 +77,8 @@ struct T3Engine {
 
     // weights (device)
     std::vector<LayerW> layers;
-    uint16_t *norm = nullptr, *text_emb = nullptr, *speech_emb = nullptr, *text_pos = nullptr, *speech_pos = nullptr, *head = nullptr;
+    std::vector<uint16_t> h_norm, h_head;   // host staging until finalize (the final norm weight is folded into the speech head)
+    uint16_t *text_emb = nullptr, *speech_emb = nullptr, *text_pos = nullptr, *speech_pos = nullptr, *head = nullptr;
     bool have[6] = {false, false, false, false, false, false};
     float *cos_t = nullptr, *sin_t = nullptr;
     int64_t weight_bytes = 0;
@@ -196,8 +197,8 @@ extern "C" int t3_destroy(T3Handle e) {
     if (!e) return T3_E_INVALID;
     (void)hipSetDevice(e->cfg.device_id);
     (void)hipStreamSynchronize(e->stream);
-    for (auto& L : e->layers) { free_dev(L.qkv); free_dev(L.o); free_dev(L.gu); free_dev(L.down); free_dev(L.ln1); free_dev(L.ln2); }
-    free_dev(e->norm); free_dev(e->text_emb); free_dev(e->speech_emb); free_dev(e->text_pos); free_dev(e->speech_pos); free_dev(e->head);
+    for (auto& L : e->layers) { free_dev(L.qkv); free_dev(L.o); free_dev(L.gu); free_dev(L.down); }
+    free_dev(e->text_emb); free_dev(e->speech_emb); free_dev(e->text_pos); free_dev(e->speech_pos); free_dev(e->head);
     free_dev(e->cos_t); free_dev(e->sin_t); free_dev(e->kv); free_dev(e->d_block_table);
     for (auto& g : e->groups) {
         if (g.stream) (void)hipStreamSynchronize(g.stream);
@@ -276,8 +277,7 @@ extern "C" int t3_load_tensor(T3Handle e, const char* name, const void* data, in
         }
         if (r == "input_layernorm.weight" || r == "post_attention_layernorm.weight") {
             if ((size_t)rows * cols != (size_t)D) return e->fail(T3_E_INVALID, std::string("bad shape for ") + name);
-            if ((rc = to_host(e, data, bytes, host))) return rc;
-            return upload(e, host.data(), D, r[0] == 'i' ? &y.ln1 : &y.ln2);
+            return to_host(e, data, bytes, r[0] == 'i' ? y.h_ln1 : y.h_ln2);
         }
         return e->fail(T3_E_NOTFOUND, std::string("unknown tensor ") + name);
     }
@@ -285,8 +285,7 @@ extern "C" int t3_load_tensor(T3Handle e, const char* name, const void* data, in
     int rc;
     if (n == "tfmr.norm.weight") {
         if ((size_t)rows * cols != (size_t)D) return e->fail(T3_E_INVALID, "bad shape for tfmr.norm.weight");
-        if ((rc = to_host(e, data, bytes, host))) return rc;
-        e->have[0] = true; return upload(e, host.data(), D, &e->norm);
+        e->have[0] = true; return to_host(e, data, bytes, e->h_norm);
     }
     struct { const char* nm; int r, c; uint16_t** dst; int idx; } tabs[] = {
         {"text_emb.weight", e->cfg.text_vocab, D, &e->text_emb, 1},
@@ -302,8 +301,7 @@ extern "C" int t3_load_tensor(T3Handle e, const char* name, const void* data, in
         }
     if (n == "speech_head.weight") {
         if (!need(V, D)) return e->fail(T3_E_INVALID, "bad shape for speech_head.weight");
-        if ((rc = to_host(e, data, bytes, host))) return rc;
-        e->have[5] = true; return upload_packed(e, host.data(), V, D, HEAD_TILES * 16, &e->head);
+        e->have[5] = true; return to_host(e, data, bytes, e->h_head);
     }
     return e->fail(T3_E_NOTFOUND, std::string("unknown tensor ") + name);   // cond_enc.*, text_head.*, tfmr.embed_tokens.* ...
 }
@@ -323,19 +321,27 @@ extern "C" int t3_finalize_weights(T3Handle e) {
     for (int i = 0; i < 6; ++i) if (!e->have[i]) return e->fail(T3_E_STATE, "missing non-layer tensor #" + std::to_string(i));
     for (int L = 0; L < e->cfg.n_layers; ++L) {
         LayerW& y = e->layers[L];
-        if (y.h_q.empty() || y.h_k.empty() || y.h_v.empty() || y.h_g.empty() || y.h_u.empty() || !y.have_o || !y.have_d || !y.ln1 || !y.ln2)
+        if (y.h_q.empty() || y.h_k.empty() || y.h_v.empty() || y.h_g.empty() || y.h_u.empty() || !y.have_o || !y.have_d || y.h_ln1.empty() || y.h_ln2.empty())
             return e->fail(T3_E_STATE, "missing tensors for layer " + std::to_string(L));
+        // the RMSNorm weights are folded into the projections that consume the normalised rows (contract: DESIGN.md "RMSNorm")
         std::vector<uint16_t> w((size_t)QKV * D), p((size_t)QKV * D);
         memcpy(w.data(), y.h_q.data(), (size_t)D * D * 2);
         memcpy(w.data() + (size_t)D * D, y.h_k.data(), (size_t)D * D * 2);
         memcpy(w.data() + (size_t)2 * D * D, y.h_v.data(), (size_t)D * D * 2);
+        fold_norm_weight(w.data(), QKV, D, y.h_ln1.data(), w.data());
         pack_weight(w.data(), QKV, D, QKV, p.data());
         if ((rc = upload(e, p.data(), p.size(), &y.qkv))) return rc;
+        fold_norm_weight(y.h_g.data(), F, D, y.h_ln2.data(), y.h_g.data());
+        fold_norm_weight(y.h_u.data(), F, D, y.h_ln2.data(), y.h_u.data());
         std::vector<uint16_t> g((size_t)2 * F * D);
         pack_gate_up(y.h_g.data(), y.h_u.data(), F, D, g.data());
         if ((rc = upload(e, g.data(), g.size(), &y.gu))) return rc;
-        y.h_q.clear(); y.h_k.clear(); y.h_v.clear(); y.h_g.clear(); y.h_u.clear();
-        y.h_q.shrink_to_fit(); y.h_k.shrink_to_fit(); y.h_v.shrink_to_fit(); y.h_g.shrink_to_fit(); y.h_u.shrink_to_fit();
+        for (auto* v : {&y.h_q, &y.h_k, &y.h_v, &y.h_g, &y.h_u, &y.h_ln1, &y.h_ln2}) { v->clear(); v->shrink_to_fit(); }
+    }
+    {
+        fold_norm_weight(e->h_head.data(), V, D, e->h_norm.data(), e->h_head.data());
+        if ((rc = upload_packed(e, e->h_head.data(), V, D, HEAD_TILES * 16, &e->head))) return rc;
+        e->h_head.clear(); e->h_head.shrink_to_fit(); e->h_norm.clear(); e->h_norm.shrink_to_fit();
     }
     // RoPE tables
     {
@@ -509,7 +515,7 @@ static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec&
         LayerW& y = e->layers[L];
         uint16_t* kvL = e->kv + (size_t)L * layer_elems;
         // 5 launches per layer: RMSNorm is folded into the qkv / gate-up GEMMs, the residual add into the o / down GEMMs
-        { Prof p(e, K_QKV, s); GemmArgs a{g.h, (const uint4*)y.qkv, M, D, QKV, g.qkv, QKV, 4, y.ln1, nullptr, 0, g.rstd}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s)); }
+        { Prof p(e, K_QKV, s); GemmArgs a{g.h, (const uint4*)y.qkv, M, D, QKV, g.qkv, QKV, 4, 1, nullptr, 0, g.rstd}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s)); }
         if (sr.n_prefill_rows == 0 && e->fuse_rope) {
             // decode-only step: every row is the newest position of its stream -> RoPE + KV write inside the attention kernel
             Prof p(e, K_ATTN, s);
@@ -519,13 +525,13 @@ static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec&
             { Prof p(e, K_ROPE, s); RopeArgs ra{g.qkv, g.qrot, kvL, g.dm.rows, e->row_stride, e->cos_t, e->sin_t, M}; HIP_TRY(launch_rope_kv(ra, s)); }
             { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot, kvL, g.dm.rows, e->row_stride, g.att, M, max_chunks, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(launch_attention(aa, s)); }
         }
-        { Prof p(e, K_O, s); GemmArgs a{g.att, (const uint4*)y.o, M, D, D, g.h, D, 16, nullptr, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
-        { Prof p(e, K_GU, s); GemmArgs a{g.h, (const uint4*)y.gu, M, D, F, g.act, F, 4, y.ln2, nullptr, 0, g.rstd}; HIP_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s)); }
-        { Prof p(e, K_DOWN, s); GemmArgs a{g.act, (const uint4*)y.down, M, F, D, g.h, D, 16, nullptr, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
+        { Prof p(e, K_O, s); GemmArgs a{g.att, (const uint4*)y.o, M, D, D, g.h, D, 16, 0, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
+        { Prof p(e, K_GU, s); GemmArgs a{g.h, (const uint4*)y.gu, M, D, F, g.act, F, 4, 1, nullptr, 0, g.rstd}; HIP_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s)); }
+        { Prof p(e, K_DOWN, s); GemmArgs a{g.act, (const uint4*)y.down, M, F, D, g.h, D, 16, 0, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
     }
     if (n_sel > 0) {
         // final RMSNorm folded into the speech-head GEMM, which gathers the sampled rows itself
-        { Prof p(e, K_HEAD, s); GemmArgs a{g.h, (const uint4*)e->head, 2 * n_sel, D, V, g.logits, VPAD, 4, e->norm, g.dm.sel_rows, HEAD_TILES}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16, 4, true), s)); }
+        { Prof p(e, K_HEAD, s); GemmArgs a{g.h, (const uint4*)e->head, 2 * n_sel, D, V, g.logits, VPAD, 4, 1, g.dm.sel_rows, HEAD_TILES}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16, 4, true), s)); }
         { Prof p(e, K_SAMPLE, s); SampleArgs sa{g.logits, VPAD, g.dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, g.dm.out_tok, e->d_dbg, n_sel}; HIP_TRY(launch_sampler(sa, s)); }
     }
     return T3_OK;

@@ -42,7 +42,7 @@ extern "C" int t3k_gemm(const void* x, const void* w, int32_t M, int32_t K, int3
     pack_weight((const uint16_t*)w, N, K, Npad, packed.data());
     DevBuf dx, dw, dout;
     K_TRY(dx.from(x, (size_t)M * K * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * N * 4, true));
-    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, K, N, dout.p, N, nw, nullptr, nullptr};
+    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, K, N, dout.p, N, nw, 0, nullptr};
     K_TRY(launch_gemm(a, EPI_F32, mt > 0 ? mt : choose_mt(M, Npad / 16, nw, false), nullptr));
     K_TRY(hipDeviceSynchronize());
     K_TRY(hipMemcpy(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
@@ -55,14 +55,15 @@ extern "C" int t3k_norm_gemm(const void* h, const void* ln_w, const void* w, int
     if (!h || !ln_w || !w || !out || M <= 0 || N <= 0 || Mh <= 0) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
     const int Npad = (N + 15) / 16 * 16;
-    std::vector<uint16_t> packed((size_t)Npad * D);
-    pack_weight((const uint16_t*)w, N, D, Npad, packed.data());
-    DevBuf dh, dl, dw, dout, dri;
-    K_TRY(dh.from(h, (size_t)Mh * D * 2)); K_TRY(dl.from(ln_w, D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2));
+    std::vector<uint16_t> folded((size_t)N * D), packed((size_t)Npad * D);
+    fold_norm_weight((const uint16_t*)w, N, D, (const uint16_t*)ln_w, folded.data());      // what the engine does once at load time
+    pack_weight(folded.data(), N, D, Npad, packed.data());
+    DevBuf dh, dw, dout, dri;
+    K_TRY(dh.from(h, (size_t)Mh * D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2));
     K_TRY(dout.alloc((size_t)M * N * 4, true));
     if (row_index) K_TRY(dri.from(row_index, (size_t)M * 4));
     DevBuf drs; K_TRY(drs.alloc((size_t)M * 4));
-    GemmArgs a{dh.as<uint16_t>(), dw.as<uint4>(), M, D, N, dout.p, N, 4, dl.as<uint16_t>(), row_index ? dri.as<int>() : nullptr, 0, drs.as<float>()};
+    GemmArgs a{dh.as<uint16_t>(), dw.as<uint4>(), M, D, N, dout.p, N, 4, 1, row_index ? dri.as<int>() : nullptr, 0, drs.as<float>()};
     K_TRY(launch_gemm(a, EPI_F32, choose_mt(M, Npad / 16, 4, true), nullptr));
     K_TRY(hipDeviceSynchronize());
     K_TRY(hipMemcpy(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
@@ -77,7 +78,7 @@ extern "C" int t3k_gemm_resid(const void* x, const void* w, int32_t M, int32_t K
     pack_weight((const uint16_t*)w, N, K, N, packed.data());
     DevBuf dx, dw, dh;
     K_TRY(dx.from(x, (size_t)M * K * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dh.from(h_bf16, (size_t)M * N * 2));
-    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, K, N, dh.p, N, 16, nullptr, nullptr};
+    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, K, N, dh.p, N, 16, 0, nullptr};
     K_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, N / 16, 16, false), nullptr));
     K_TRY(hipDeviceSynchronize());
     K_TRY(hipMemcpy(h_bf16, dh.p, (size_t)M * N * 2, hipMemcpyDeviceToHost));
@@ -88,12 +89,14 @@ extern "C" int t3k_gemm_resid(const void* x, const void* w, int32_t M, int32_t K
 extern "C" int t3k_silu_mul_gemm(const void* h, const void* ln_w, const void* wg, const void* wu, int32_t M, int32_t Fd, void* out) {
     if (!h || !ln_w || !wg || !wu || !out || M <= 0 || Fd <= 0 || Fd % 16) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
-    std::vector<uint16_t> packed((size_t)2 * Fd * D);
-    pack_gate_up((const uint16_t*)wg, (const uint16_t*)wu, Fd, D, packed.data());
-    DevBuf dx, dl, dw, dout;
-    K_TRY(dx.from(h, (size_t)M * D * 2)); K_TRY(dl.from(ln_w, D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * Fd * 2, true));
+    std::vector<uint16_t> fg((size_t)Fd * D), fu((size_t)Fd * D), packed((size_t)2 * Fd * D);
+    fold_norm_weight((const uint16_t*)wg, Fd, D, (const uint16_t*)ln_w, fg.data());
+    fold_norm_weight((const uint16_t*)wu, Fd, D, (const uint16_t*)ln_w, fu.data());
+    pack_gate_up(fg.data(), fu.data(), Fd, D, packed.data());
+    DevBuf dx, dw, dout;
+    K_TRY(dx.from(h, (size_t)M * D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * Fd * 2, true));
     DevBuf drs; K_TRY(drs.alloc((size_t)M * 4));
-    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, D, Fd, dout.p, Fd, 4, dl.as<uint16_t>(), nullptr, 0, drs.as<float>()};
+    GemmArgs a{dx.as<uint16_t>(), dw.as<uint4>(), M, D, Fd, dout.p, Fd, 4, 1, nullptr, 0, drs.as<float>()};
     K_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, Fd / 16, 4, true), nullptr));
     K_TRY(hipDeviceSynchronize());
     K_TRY(hipMemcpy(out, dout.p, (size_t)M * Fd * 2, hipMemcpyDeviceToHost));

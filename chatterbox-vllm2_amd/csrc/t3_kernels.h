@@ -26,12 +26,12 @@ enum GemmEpi { EPI_F32 = 0, EPI_BF16 = 1, EPI_RESID = 2, EPI_SILU = 3 };
 
 struct GemmArgs {
     const uint16_t* X;   // [M][K] bf16 row-major (NORM form: the un-normalised residual stream)
-    const uint4* Wp;     // packed weight, see pack_weight()
+    const uint4* Wp;     // packed weight, see pack_weight() (NORM form: with the norm weight folded in, fold_norm_weight())
     int M, K, N;         // N = number of valid output columns (EPI_SILU: F)
     void* out;           // EPI_F32: float [M][ldo]; else bf16 [M][ldo]; EPI_RESID: residual stream, updated in place
     int ldo;
     int nw;              // waves = K segments per workgroup: 4 (qkv, gate/up, head) or 16 (o_proj, down_proj)
-    const uint16_t* ln_w;    // non-null: fold RMSNorm with this weight [1024] into the GEMM (K = 1024, nw = 4)
+    int norm;                // 1: NORM form -- scale every row by rstd = 1/sqrt(mean(x^2) + eps) in the epilogue (K = 1024, nw = 4)
     const int* row_index;    // optional gather: source row of X per GEMM row (speech head over the sampled rows)
     int packed_tiles = 0;    // > 0: the packed weight holds this many n-tiles (zero rows beyond N), so tile groups may overhang N
     float* rstd_scratch = nullptr;   // [M] floats: lets the NORM forms take the prefill-sized schedule (row statistic in its own pass)
@@ -42,6 +42,8 @@ struct GemmArgs {
 void pack_weight(const uint16_t* W, int N, int K, int Npad, uint16_t* out);
 // gate/up interleave: packed tile 2t = gate tile t, 2t+1 = up tile t.
 void pack_gate_up(const uint16_t* Wg, const uint16_t* Wu, int Fdim, int K, uint16_t* out);
+// W'[n][k] = bf16(W[n][k] * ln[k]) (host): an RMSNorm weight folded into the projection behind it, before packing
+void fold_norm_weight(const uint16_t* W, int N, int K, const uint16_t* ln, uint16_t* out);
 
 int choose_mt(int M, int ntiles_x, int nw = 4, bool norm = false);
 hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s);
@@ -88,22 +90,6 @@ struct AttnArgs {
     const float *cos_t, *sin_t;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
-
-// Persistent layer chain (chain_kernel.hip): o_proj(+residual) -> gate/up -> down_proj(+residual) -> next layer's qkv in one launch.
-constexpr int CHAIN_WGS = 256;                    // one workgroup per CU
-struct ChainArgs {
-    const uint4 *Wo, *Wgu, *Wd, *Wqkv;            // packed weights of this layer; Wqkv = the NEXT layer's qkv (phase bit 3)
-    const uint16_t *ln2, *ln1n;                   // this layer's post-attention norm weight, the next layer's input norm weight
-    const uint16_t* att;                          // [M][1024] attention output (previous launch)
-    uint16_t* h;                                  // [M][1024] residual stream, updated in place
-    uint16_t* act;                                // [M][4096] scratch
-    uint16_t* qkv;                                // [M][3072] out
-    int M;                                        // rows, <= 64
-    int phases;                                   // bit 0 o, bit 1 gate/up, bit 2 down, bit 3 qkv (executed in this order)
-    unsigned* flags;                              // [CHAIN_WGS] barrier epochs, zeroed once at allocation, never reset
-    unsigned* err;                                // set to 1 when a barrier wait gave up
-};
-hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
 
 struct SampleArgs {
     const uint16_t* logits;    // [2*n][ldl] bf16: row 2i cond, 2i+1 uncond

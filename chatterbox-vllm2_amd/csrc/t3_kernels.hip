@@ -16,6 +16,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <utility>
+
 namespace t3 {
 
 // ------------------------------------------------------------------------------------------------
@@ -27,11 +29,11 @@ namespace t3 {
 // identified on-device and is restated in the checker); four consecutive segments give a group sum
 // G = ((s0 + s1) + s2) + s3 in fp32; with 16 segments (o_proj, down_proj) the result is ((G0 + G1) + G2) + G3.
 //
-// NORM form (qkv, gate/up, speech head; K = 1024, NW = 4): the RMSNorm that precedes the projection is
-// folded in -- the A operand is bf16(h * w_ln) formed in registers, the row statistic sum(h^2) is accumulated
-// from the very fragments the wave streams anyway, and the epilogue scales by rstd = 1/sqrt(ss/1024 + eps).
-// Statistic order: per wave (segment) and lane group q: sequential h*h adds over its 64 elements (kb outer, j
-// inner); butterfly over q (xor 16, xor 32); the four segment sums fold ((S0 + S1) + S2) + S3.
+// NORM form (qkv, gate/up, speech head; K = 1024, NW = 4): the RMSNorm that precedes the projection is folded in -- its
+// weight into the packed matrix at load time (W' = bf16(W * w_ln), fold_norm_weight()), its row statistic sum(h^2) onto the
+// matrix cores (a wave multiplies its A fragments with themselves and reads the diagonal: the same MFMA chain per segment as
+// the GEMM itself), and rstd = 1/sqrt(ss/1024 + eps) into the epilogue.  The activations reach the MFMAs untouched.
+// Statistic order: per wave (segment) one chain from +0 in ascending k; the four segment sums fold ((S0 + S1) + S2) + S3.
 //
 // One workgroup = NW waves = NT n-tiles of 16 columns x MT m-tiles of 16 rows.  Weights are packed so that a
 // wave's weight load is one contiguous 1 KiB (pack_weight); activations are read row-major, 16 rows x 64 B
@@ -45,10 +47,10 @@ __device__ unsigned long long g_gemm_clk[8][2048][5];
 #else
 #define T3_GSTAMP(i)
 #endif
-template <int MT, int NT, int EPI, int PD, int NW, bool NORM>
+template <int MT, int NT, int EPI, int PD, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
     T3_GSTAMP(0);
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [NW waves][MT*NT][4 regs][64 lanes] | NORM: [4][MT*16] row sums
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [NW waves][MT*NT][4 regs][64 lanes]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int KB = a.K >> 5, kbs = KB / NW, kb0 = wave * kbs;
@@ -67,15 +69,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         xp[i] = reinterpret_cast<const uint4*>(a.X + q * 8 + c * 32);
 #endif
     }
-    const uint4* lnp = NORM ? reinterpret_cast<const uint4*>(a.ln_w + kb0 * 32 + q * 8) : nullptr;
     f32x4 acc[MT][NT];
-    float ssq[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        ssq[i] = 0.0f;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
 
     // every thread finishes MT*NT*256 / (64*NW) outputs; D[row = 4*(lane>>4) + reg][col = lane&15]
     constexpr int TOTAL = MT * NT * 256, STEP = NW * 64, ITER = (TOTAL + STEP - 1) / STEP;
@@ -92,7 +90,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
         }
     }
 
-    uint4 wr[PD][NT], xr[PD][MT], lr[PD];
+    uint4 wr[PD][NT], xr[PD][MT];
 #pragma unroll
     for (int j = 0; j < PD; ++j)
         if (j < kbs) {
@@ -100,26 +98,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             for (int t = 0; t < NT; ++t) wr[j][t] = ld_nt(wp[t] + j * 64);
 #pragma unroll
             for (int i = 0; i < MT; ++i) xr[j][i] = xp[i][j * 4];
-            if (NORM) lr[j] = lnp[j * 4];
         }
     for (int kbase = 0; kbase < kbs; kbase += PD) {
 #pragma unroll
         for (int j = 0; j < PD; ++j) {
             const int kb = kbase + j;
             if (kb < kbs) {
-                if constexpr (NORM) {
-                    float lw[8]; unpack8(lr[j], lw);
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        float xf[8]; unpack8(xr[j][i], xf);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ssq[i] = __builtin_fmaf(xf[e], xf[e], ssq[i]);
-                        uint4 o;
-                        o.x = cvt_pk(xf[0] * lw[0], xf[1] * lw[1]); o.y = cvt_pk(xf[2] * lw[2], xf[3] * lw[3]);
-                        o.z = cvt_pk(xf[4] * lw[4], xf[5] * lw[5]); o.w = cvt_pk(xf[6] * lw[6], xf[7] * lw[7]);
-                        xr[j][i] = o;
-                    }
-                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -131,7 +115,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
                     for (int t = 0; t < NT; ++t) wr[j][t] = ld_nt(wp[t] + (kb + PD) * 64);
 #pragma unroll
                     for (int i = 0; i < MT; ++i) xr[j][i] = xp[i][(kb + PD) * 4];
-                    if (NORM) lr[j] = lnp[(kb + PD) * 4];
                 }
             }
         }
@@ -139,21 +122,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
 
     T3_GSTAMP(2);
     // cross-wave (= cross-segment) reduction in segment order
-    float* rowsum = red + (size_t)NW * MT * NT * 256;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[((wave * (MT * NT) + i * NT + t) * 4 + r) * 64 + lane] = acc[i][t][r];
-    if constexpr (NORM) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            float v = ssq[i];
-            v = v + __shfl_xor(v, 16); v = v + __shfl_xor(v, 32);
-            if (q == 0) rowsum[wave * (MT * 16) + i * 16 + c] = v;
-        }
-    }
     __syncthreads();
     T3_GSTAMP(3);
 
@@ -181,13 +155,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
             }
             v[u] = tot;
         }
-        if constexpr (NORM) {
-            const int rl = i * 16 + 4 * (l2 >> 4) + r;
-            const float ss = ((rowsum[rl] + rowsum[MT * 16 + rl]) + rowsum[2 * MT * 16 + rl]) + rowsum[3 * MT * 16 + rl];
-            const float rstd = 1.0f / sqrtf(ss * (1.0f / 1024.0f) + 1e-5f);
-#pragma unroll
-            for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u) v[u] = v[u] * rstd;
-        }
         if constexpr (EPI == EPI_SILU) {
             const int n = (blockIdx.x * (NT / 2) + (t >> 1)) * 16 + (l2 & 15);      // tile pair index == output tile index
             if (n < a.N)
@@ -208,30 +175,240 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm2_kernel: the decode schedule of the NORM forms (NW = 4, K = 1024, MT <= 2) and of the 16-segment forms at one
+// m-tile per workgroup (o_proj / down_proj).  Same numbers as gemm_kernel, two differences in how the bytes move:
+//   * A operand: a wave reads its K slice of its 16 rows as FULL row segments (KBS * 64 contiguous bytes per row, whole
+//     128-byte lines) into a wave-private, XOR-swizzled LDS image and takes its MFMA fragments from there with ds_read_b128.
+//     The fragment-shaped global loads of gemm_kernel (16 rows x 64 B per instruction, half lines) cost the texture path twice
+//     the cycles per byte: at 64 rows the activations were 3.8 us of a 29 us layer (tools/chain_proto.hip, -DT3_GEMM_XDUMMY).
+//   * every weight tile of the wave's K slice is requested up front (KBS * NT KiB in flight per wave, no refill logic), behind
+//     the A loads, so the A image is in LDS while the weights are still in flight.
+// The partial sums of the cross-wave fold reuse the wave's own A image (dead after the K loop), so LDS = the A images only.
+// NORM: rstd from the MFMA diagonal (see the header of this section); the weights carry the norm weight already.
+// ------------------------------------------------------------------------------------------------
+// Loads whose ISSUE ORDER matters (gemm2_kernel): inline asm, so hipcc neither reorders nor counts them.  Every wait below is
+// hand-counted (vmcnt retires in issue order), and names the registers it releases as read-write operands, so no consumer can be
+// scheduled above it (cdna_hip_programming.md 5.7, form (ii)).
+typedef unsigned int uint4_v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gload16(uint4_v& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void gload16_nt(uint4_v& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(d) : "v"(p) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <typename Fn, int... Is>
+__device__ __forceinline__ void static_for(Fn&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+__device__ __forceinline__ void landed(uint4_v& d) { asm volatile("" : "+v"(d)); }          // d is defined from here on
+__device__ __forceinline__ bf16x8 as_frag4(const uint4_v& v) { union { uint4_v u; bf16x8 f; } c; c.u = v; return c.f; }
+template <int KBS>
+__device__ __forceinline__ unsigned a_img_off(int row, int ch) {     // byte offset of 16-byte chunk ch of row `row` in a wave's A image
+    if constexpr (KBS >= 4) return (unsigned)(row * (KBS * 64) + ((ch ^ (row & 15)) << 4));        // >= 256-byte rows: one row per bank row
+    else return (unsigned)(row * (KBS * 64) + ((ch ^ ((row >> 1) & (KBS * 4 - 1))) << 4));          // 128-byte rows: two rows per bank row
+}
+
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
+__global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];      // [NW waves][MT][16 rows][KBS * 64 B] | NORM: float [NW][MT*16]
+    static_assert(NT <= KBS && (KBS == 8 || KBS == 2) && (NW == 4 || NW == 16), "gemm2 shapes");
+    constexpr int LPR = KBS * 4, RPI = 64 / LPR;                // lanes (= 16-byte chunks) per row slice, rows per wave instruction
+    constexpr int ABYTES = MT * KBS * 1024, TILES = MT * NT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int KB = a.K >> 5, kb0 = wave * KBS;
+    unsigned char* aimg = lds2 + (size_t)wave * ABYTES;
+    float* rowsum = reinterpret_cast<float*>(lds2 + (size_t)NW * ABYTES);
+
+    // EPI_RESID (16-wave form, one output per thread): the residual operand is requested first (a compiler-counted load: it must be older than the asm loads)
+    uint16_t hres = 0;
+    if constexpr (EPI == EPI_RESID) {
+        const int r = (tid >> 6) & 3, l2 = tid & 63;
+        const int m = blockIdx.y * 16 + 4 * (l2 >> 4) + r, n = blockIdx.x * 16 + (l2 & 15);
+        if (tid < 256 && m < a.M && n < a.N) hres = reinterpret_cast<const uint16_t*>(a.out)[(size_t)m * a.ldo + n];
+    }
+    // ---- A: full row segments of this wave's K slice
+    uint4_v ar[MT][KBS];
+    const int rsub = lane / LPR, ch = lane % LPR;
+    int mrow[MT][KBS];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < KBS; ++t) {
+            const int m = (blockIdx.y * MT + i) * 16 + t * RPI + rsub;
+            mrow[i][t] = m < a.M ? m : a.M - 1;        // padded rows re-read the last row; their outputs are dropped
+        }
+    if (a.row_index) {                                 // ONE branch around all the gather loads (a select per element would serialise them)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < KBS; ++t) mrow[i][t] = a.row_index[mrow[i][t]];
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < KBS; ++t)
+            gload16(ar[i][t], a.X + (size_t)mrow[i][t] * a.K + kb0 * 32 + ch * 8);
+    // ---- W: every tile of this wave's K slice, behind the A loads and before the first wait (left to itself, hipcc sinks these
+    // loads below the staging block to save registers, i.e. behind a full L2 round trip)
+    uint4_v wr[KBS][NT];
+#pragma unroll
+    for (int kb = 0; kb < KBS; ++kb)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gload16_nt(wr[kb][t], a.Wp + ((size_t)(blockIdx.x * NT + t) * KB + kb0 + kb) * 64 + lane);
+    // ---- stage A (wave-private: a wave's DS operations execute in order, no barrier).  The KBS * NT weight loads are younger.
+    wait_vmcnt<KBS * NT>();
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < KBS; ++t) landed(ar[i][t]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < KBS; ++t)
+            *reinterpret_cast<uint4_v*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(t * RPI + rsub, ch)) = ar[i][t];
+    asm volatile("" ::: "memory");
+    f32x4 acc[MT][NT], ss[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        ss[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    static_for([&](auto kbc) {
+        constexpr int kb = decltype(kbc)::value;
+        uint4 af[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(c, 4 * kb + q));
+        wait_vmcnt<(KBS - 1 - kb) * NT>();            // this k-block's NT weight tiles have landed ((KBS - 1 - kb) * NT younger loads may still fly)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) landed(wr[kb][t]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if constexpr (NORM) ss[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(af[i]), ss[i], 0, 0, 0);   // diagonal = sum of squares
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][t]), acc[i][t], 0, 0, 0);
+        }
+    }, std::make_integer_sequence<int, KBS>{});
+    // ---- partials over the wave's own (now dead) A image: [tile][r][lane]
+    asm volatile("" ::: "memory");
+    float* redw = reinterpret_cast<float*>(aimg);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) redw[((i * NT + t) * 4 + r) * 64 + lane] = acc[i][t][r];
+    if constexpr (NORM) {
+        // D[row = 4 q + r][col = c]: the diagonal element of row c sits in lane group q = c / 4, register c % 4
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int r = c & 3;
+            const float d = r == 0 ? ss[i][0] : r == 1 ? ss[i][1] : r == 2 ? ss[i][2] : ss[i][3];
+            if ((c >> 2) == q) rowsum[wave * (MT * 16) + i * 16 + c] = d;
+        }
+    }
+    __syncthreads();
+    auto part = [&](int w) { return reinterpret_cast<const float*>(lds2 + (size_t)w * ABYTES); };
+
+    if constexpr (NW == 4) {
+        // four outputs (one row, four columns) per thread and step: 16-byte LDS reads, 8-byte stores
+        constexpr int NTO = (EPI == EPI_SILU) ? NT / 2 : NT, PIECES = MT * NTO * 64, PIT = (PIECES + 255) / 256;
+#pragma unroll
+        for (int k = 0; k < PIT; ++k) {
+            const int p = tid + k * 256;
+            if (p >= PIECES) continue;
+            const int ito = p >> 6, r16 = (p >> 2) & 15, qq = p & 3;
+            const int i = ito / NTO, to = ito % NTO;
+            const int m = (blockIdx.y * MT + i) * 16 + r16;
+            if (m >= a.M) continue;
+            const int g = r16 >> 2, r = r16 & 3;
+            float v[EPI == EPI_SILU ? 2 : 1][4];
+#pragma unroll
+            for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u) {
+                const int it = i * NT + (EPI == EPI_SILU ? 2 * to + u : to);
+                const int o = (it * 4 + r) * 64 + 16 * g + 4 * qq;
+                const float4 s0 = *reinterpret_cast<const float4*>(part(0) + o), s1 = *reinterpret_cast<const float4*>(part(1) + o),
+                             s2 = *reinterpret_cast<const float4*>(part(2) + o), s3 = *reinterpret_cast<const float4*>(part(3) + o);
+                v[u][0] = ((s0.x + s1.x) + s2.x) + s3.x; v[u][1] = ((s0.y + s1.y) + s2.y) + s3.y;
+                v[u][2] = ((s0.z + s1.z) + s2.z) + s3.z; v[u][3] = ((s0.w + s1.w) + s2.w) + s3.w;
+            }
+            if constexpr (NORM) {
+                const int rl = i * 16 + r16;
+                const float ssum = ((rowsum[rl] + rowsum[MT * 16 + rl]) + rowsum[2 * MT * 16 + rl]) + rowsum[3 * MT * 16 + rl];
+                const float rstd = 1.0f / sqrtf(ssum * (1.0f / 1024.0f) + 1e-5f);
+#pragma unroll
+                for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[u][e] = v[u][e] * rstd;
+            }
+            const int n = (blockIdx.x * NTO + to) * 16 + 4 * qq;
+            if (n >= a.N) continue;
+            if constexpr (EPI == EPI_F32) {
+                float* op = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n + e < a.N) op[e] = v[0][e];
+            } else {
+                uint32_t ob[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ob[e] = (EPI == EPI_SILU) ? silu_mul_bf(f2bf(v[0][e]), f2bf(v[EPI == EPI_SILU ? 1 : 0][e])) : f2bf(v[0][e]);
+                uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
+                if (n + 3 < a.N || a.ldo >= ((a.N + 3) & ~3)) *reinterpret_cast<uint2*>(op) = make_uint2(ob[0] | (ob[1] << 16), ob[2] | (ob[3] << 16));
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < a.N) op[e] = (uint16_t)ob[e];
+                }
+            }
+        }
+    } else {
+        // 16 segments: one output per thread (256 of the 1024 threads), ((G0 + G1) + G2) + G3 with G = ((s0 + s1) + s2) + s3
+        if (tid < 256) {
+            const int r = (tid >> 6) & 3, l2 = tid & 63;
+            const int m = blockIdx.y * 16 + 4 * (l2 >> 4) + r, n = blockIdx.x * 16 + (l2 & 15);
+            if (m < a.M && n < a.N) {
+                const int o = r * 64 + l2;
+                float tot = 0.0f;
+#pragma unroll
+                for (int gsum = 0; gsum < 4; ++gsum) {
+                    float s4 = part(4 * gsum)[o];
+                    s4 = s4 + part(4 * gsum + 1)[o]; s4 = s4 + part(4 * gsum + 2)[o]; s4 = s4 + part(4 * gsum + 3)[o];
+                    tot = gsum == 0 ? s4 : tot + s4;
+                }
+                if constexpr (EPI == EPI_F32) reinterpret_cast<float*>(a.out)[(size_t)m * a.ldo + n] = tot;
+                else if constexpr (EPI == EPI_BF16) reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)f2bf(tot);
+                else reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)f2bf(bf2f(hres) + rbf(tot));     // EPI_RESID: h = bf16(h + bf16(y))
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Prefill-sized GEMM (M >= 256 rows): the same numbers as gemm_kernel, another schedule.  A workgroup of four waves owns a
 // 128-row x 64-column tile (4 packed n-tiles); every K step of 32 is staged once through LDS (activations 128 x 64 B row
-// pieces -- RMSNorm weight applied on the way in; weights: 4 packed 1 KiB fragments) and feeds 32 MFMAs, so a weight byte is
+// pieces; weights: 4 packed 1 KiB fragments, the NORM forms' carrying the norm weight) and feeds 32 MFMAs, so a weight byte is
 // re-read once per 128 rows instead of once per 32 and an activation byte once per 64 columns instead of once per workgroup.
 // Contract order per output: one MFMA chain per K segment FROM ZERO in ascending k; segments folded left to right in groups
 // of four (G = ((s0 + s1) + s2) + s3), groups folded left to right -- hence three accumulator sets (segment, group, total).
-// The row statistic of the NORM forms comes from row_rstd_kernel (same partial sums as gemm_kernel's own).
+// The row statistic of the NORM forms comes from row_rstd_kernel (the same MFMA chains as gemm2_kernel's own).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void row_rstd_kernel(const uint16_t* h, float* rstd, int rows) {
-    // 16 lanes per row: lane (s = segment of 256, q = lane group of the A fragment) adds h^2 over k = 256 s + 32 kb + 8 q + j
-    const int lane = threadIdx.x & 63, l16 = lane & 15, sg = l16 >> 2, q = l16 & 3;
-    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-    const int rr = row < rows ? row : rows - 1;
-    const uint16_t* hr = h + (size_t)rr * D + sg * 256 + q * 8;
-    float a = 0.0f;
-    for (int kb = 0; kb < 8; ++kb) {
-        float xf[8]; unpack8(*reinterpret_cast<const uint4*>(hr + kb * 32), xf);
+    // one wave per 16 rows: per segment of 256 k the wave multiplies its A fragments with themselves (one MFMA chain from +0,
+    // ascending k) and keeps the diagonal; the four segment sums fold ((S0 + S1) + S2) + S3 -- gemm2_kernel's own statistic
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int mt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (mt * 16 >= rows) return;
+    int m = mt * 16 + c; m = m < rows ? m : rows - 1;
+    const uint4* xp = reinterpret_cast<const uint4*>(h + (size_t)m * D + q * 8);
+    float tot = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a = __builtin_fmaf(xf[e], xf[e], a);
+    for (int sg = 0; sg < 4; ++sg) {
+        f32x4 ss = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const uint4 af = xp[(sg * 8 + kb) * 4];
+            ss = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag(af), ss, 0, 0, 0);
+        }
+        const int r = c & 3;
+        const float d = r == 0 ? ss[0] : r == 1 ? ss[1] : r == 2 ? ss[2] : ss[3];
+        tot = sg == 0 ? d : tot + d;
     }
-    a = a + __shfl_xor(a, 1); a = a + __shfl_xor(a, 2);          // over q: (p0 + p1) + (p2 + p3)
-    const float s0 = __shfl(a, (lane & 48) + 0), s1 = __shfl(a, (lane & 48) + 4), s2 = __shfl(a, (lane & 48) + 8), s3 = __shfl(a, (lane & 48) + 12);
-    const float ss = ((s0 + s1) + s2) + s3;
-    if (l16 == 0 && row < rows) rstd[row] = 1.0f / sqrtf(ss * (1.0f / 1024.0f) + 1e-5f);
+    if ((c >> 2) == q && mt * 16 + c < rows) rstd[mt * 16 + c] = 1.0f / sqrtf(tot * (1.0f / 1024.0f) + 1e-5f);
 }
 
 template <int EPI, int NSEG, bool NORM>
@@ -249,24 +426,17 @@ __global__ __launch_bounds__(256, NSEG == 4 ? 4 : 2) void pgemm_kernel(GemmArgs 
         int m = m0 + row; m = m < a.M ? m : a.M - 1;
         xsrc[j] = reinterpret_cast<const uint4*>(a.X + (size_t)m * a.K + q * 8);
     }
-    const uint4* lnsrc = NORM ? reinterpret_cast<const uint4*>(a.ln_w + (t & 3) * 8) : nullptr;
     const uint4* wsrc = a.Wp + ((size_t)(nt0 + (t >> 6)) * KB) * 64 + lane;
-    uint4 xa[2], wb, lw;
+    uint4 xa[2], wb;
     auto fetch = [&](int kb) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) xa[j] = xsrc[j][kb * 4];
         wb = ld_nt(wsrc + (size_t)kb * 64);
-        if (NORM) lw = lnsrc[kb * 4];
     };
     auto stage = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            uint4 v = xa[j];
-            if constexpr (NORM) {
-                float xf[8], lf[8]; unpack8(v, xf); unpack8(lw, lf);
-                v.x = cvt_pk(xf[0] * lf[0], xf[1] * lf[1]); v.y = cvt_pk(xf[2] * lf[2], xf[3] * lf[3]);
-                v.z = cvt_pk(xf[4] * lf[4], xf[5] * lf[5]); v.w = cvt_pk(xf[6] * lf[6], xf[7] * lf[7]);
-            }
+            const uint4 v = xa[j];
             As[buf][t + 256 * j] = v;
         }
         Bs[buf][t] = wb;
@@ -349,13 +519,13 @@ void set_pgemm_min_rows(int rows) { g_pgemm_min_rows = rows; }
 
 // Large-M path of launch_gemm: returns hipErrorNotSupported when the shape is not one of the layer forms.
 static hipError_t launch_pgemm(const GemmArgs& a, int epi, hipStream_t s) {
-    const bool norm = a.ln_w != nullptr;
+    const bool norm = a.norm != 0;
     const int nseg = a.nw == 16 ? 16 : 4;
     const int ntiles = (a.N + 15) / 16 * (epi == EPI_SILU ? 2 : 1);
     if (a.row_index || ntiles % 4 || a.K % (32 * nseg) || (norm && (!a.rstd_scratch || a.K != D))) return hipErrorNotSupported;
     const dim3 grid(ntiles / 4, (a.M + 127) / 128);
     if (norm) {
-        hipLaunchKernelGGL(row_rstd_kernel, dim3((a.M + 15) / 16), dim3(256), 0, s, a.X, a.rstd_scratch, a.M);
+        hipLaunchKernelGGL(row_rstd_kernel, dim3((a.M + 63) / 64), dim3(256), 0, s, a.X, a.rstd_scratch, a.M);
         if (epi == EPI_BF16) hipLaunchKernelGGL((pgemm_kernel<EPI_BF16, 4, true>), grid, dim3(256), 0, s, a, (const float*)a.rstd_scratch);
         else if (epi == EPI_F32) hipLaunchKernelGGL((pgemm_kernel<EPI_F32, 4, true>), grid, dim3(256), 0, s, a, (const float*)a.rstd_scratch);
         else if (epi == EPI_SILU) hipLaunchKernelGGL((pgemm_kernel<EPI_SILU, 4, true>), grid, dim3(256), 0, s, a, (const float*)a.rstd_scratch);
@@ -372,12 +542,12 @@ static hipError_t launch_pgemm(const GemmArgs& a, int epi, hipStream_t s) {
 int choose_mt(int M, int ntiles_x, int nw, bool norm) {
     const int mtiles = (M + 15) / 16;
     if (const char* e = getenv("T3_GEMM_MT")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) return v; }
-    // Largest row tile that (a) fits the register file (NORM form: 2 m-tiles; 16-wave form: 4) and (b) still launches
+    // Largest row tile that (a) fits the register file / LDS (NORM form: 2 m-tiles; 16-wave form: 4) and (b) still launches
     // enough workgroups: >= 512 for the 4-wave forms (measured: qkv is fastest at 768 workgroups, gate/up at 512),
     // >= 256 for the 16-wave form.  Workgroups with the same blockIdx.x differ by a multiple of gridDim.x in linear id,
     // and gridDim.x is a multiple of 8 for the layer GEMMs, so they land on the same XCD and share the weight tile in L2.
     int cap = norm ? 2 : (nw == 16 ? 4 : 8);
-    if (norm) { if (const char* e = getenv("T3_GEMM_MT_NORM")) cap = atoi(e); }
+    if (norm) { if (const char* e = getenv("T3_GEMM_MT_NORM")) cap = atoi(e) >= 2 ? 2 : 1; }
     const long want = nw == 16 ? 256 : 512;
     int best = 1;
     for (int mt = 1; mt <= cap; mt <<= 1) {
@@ -388,34 +558,73 @@ int choose_mt(int M, int ntiles_x, int nw, bool norm) {
     return best;
 }
 
-template <int MT, int NT, int EPI, int NW, bool NORM>
+template <int MT, int NT, int EPI, int NW>
 static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     // ring depth, bounded by the register file: 4-wave workgroups may use ~200 VGPRs, 16-wave ones 128
-#ifndef T3_PD16
-#define T3_PD16 4
-#endif
-#ifndef T3_PDN4
-#define T3_PDN4 4
-#endif
-    constexpr int PD = NW == 16 ? (MT <= 2 ? T3_PD16 : 2) : (NORM ? (MT * NT <= 2 ? 8 : T3_PDN4) : ((MT + NT) <= 6 ? 8 : 4));
+    constexpr int PD = NW == 16 ? (MT <= 2 ? 4 : 2) : ((MT + NT) <= 6 ? 8 : 4);
     const int ntiles = (a.N + 15) / 16;           // EPI_SILU: N = F -> one workgroup per output tile (2 packed tiles)
     const int gx = (EPI == EPI_SILU) ? (ntiles + NT / 2 - 1) / (NT / 2) : (ntiles + NT - 1) / NT;
     const int gy = ((a.M + 15) / 16 + MT - 1) / MT;
-    const size_t lds = ((size_t)NW * MT * NT * 256 + (NORM ? 4 * MT * 16 : 0)) * sizeof(float);
-    auto kern = gemm_kernel<MT, NT, EPI, PD, NW, NORM>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NW * 64), lds, s, a);
+    const size_t lds = (size_t)NW * MT * NT * 256 * sizeof(float);        // <= 64 KiB for every instantiation below
+    hipLaunchKernelGGL((gemm_kernel<MT, NT, EPI, PD, NW>), dim3(gx, gy), dim3(NW * 64), lds, s, a);
     return hipGetLastError();
 }
 
-// epi: GemmEpi; nw: 4 (qkv / gate-up / head form) or 16 (o_proj / down_proj form); norm: fold RMSNorm (needs K = 1024, nw = 4)
+// gemm2_kernel launcher; a == nullptr: only raise the kernel's dynamic-LDS limit (prepare_kernels, before any stream capture)
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
+static hipError_t launch_gemm2_t(const GemmArgs* a, hipStream_t s) {
+    constexpr size_t lds = (size_t)NW * MT * KBS * 1024 + (NORM ? (size_t)NW * MT * 16 * sizeof(float) : 0);
+    auto kern = gemm2_kernel<MT, NT, EPI, NW, KBS, NORM>;
+    static bool raised = false;
+    if (!raised && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    if (!a) return hipSuccess;
+    const int ntiles = a->packed_tiles > 0 ? a->packed_tiles / (EPI == EPI_SILU ? 2 : 1) : (a->N + 15) / 16;
+    const int gx = (EPI == EPI_SILU) ? (ntiles + NT / 2 - 1) / (NT / 2) : (ntiles + NT - 1) / NT;
+    const int gy = ((a->M + 15) / 16 + MT - 1) / MT;
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NW * 64), lds, s, *a);
+    return hipGetLastError();
+}
+// NORM forms (4 waves, K = 1024): MT in {1, 2}, NT in {1, 2, 3, 4}
+static hipError_t launch_gemm2_norm(const GemmArgs* a, int epi, int mt, int nt, hipStream_t s) {
+#define T3_G2(E, MTV, NTV) return launch_gemm2_t<MTV, NTV, E, 4, 8, true>(a, s)
+#define T3_G2_NT(E, MTV) switch (nt) { case 1: T3_G2(E, MTV, 1); case 2: T3_G2(E, MTV, 2); case 3: T3_G2(E, MTV, 3); default: T3_G2(E, MTV, 4); }
+    if (epi == EPI_F32) { if (mt >= 2) T3_G2(EPI_F32, 2, 1); else T3_G2(EPI_F32, 1, 1); }
+    if (epi == EPI_BF16) { if (mt >= 2) { T3_G2_NT(EPI_BF16, 2) } else { T3_G2_NT(EPI_BF16, 1) } }
+    if (epi == EPI_SILU) {
+        if (mt >= 2) { if (nt == 4) T3_G2(EPI_SILU, 2, 4); else T3_G2(EPI_SILU, 2, 2); }
+        else { if (nt == 4) T3_G2(EPI_SILU, 1, 4); else T3_G2(EPI_SILU, 1, 2); }
+    }
+#undef T3_G2_NT
+#undef T3_G2
+    return hipErrorInvalidValue;
+}
+// 16-segment forms at one m-tile per workgroup: K = 1024 (o_proj, 64-wide segments) or K = 4096 (down_proj, 256-wide segments)
+static hipError_t launch_gemm2_16(const GemmArgs* a, int epi, int kbs, hipStream_t s) {
+    if (epi == EPI_RESID) return kbs == 2 ? launch_gemm2_t<1, 1, EPI_RESID, 16, 2, false>(a, s) : launch_gemm2_t<1, 1, EPI_RESID, 16, 8, false>(a, s);
+    if (epi == EPI_F32) return kbs == 2 ? launch_gemm2_t<1, 1, EPI_F32, 16, 2, false>(a, s) : launch_gemm2_t<1, 1, EPI_F32, 16, 8, false>(a, s);
+    return hipErrorInvalidValue;
+}
+hipError_t prepare_gemm2() {
+    hipError_t e;
+    for (int epi : {EPI_F32, EPI_BF16, EPI_SILU})
+        for (int mt = 1; mt <= 2; ++mt)
+            for (int nt = 1; nt <= 4; ++nt)
+                if ((e = launch_gemm2_norm(nullptr, epi, mt, nt, nullptr)) != hipSuccess) return e;
+    for (int epi : {EPI_F32, EPI_RESID})
+        for (int kbs : {2, 8})
+            if ((e = launch_gemm2_16(nullptr, epi, kbs, nullptr)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+// epi: GemmEpi; nw: 4 (qkv / gate-up / head form) or 16 (o_proj / down_proj form); a.norm: RMSNorm folded (needs K = 1024, nw = 4)
 hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     const int nw = a.nw == 16 ? 16 : 4;
-    const bool norm = a.ln_w != nullptr;
+    const bool norm = a.norm != 0;
     if (a.K % (32 * nw) != 0 || (norm && (a.K != D || nw != 4))) return hipErrorInvalidValue;
     if (nw == 16 && mt > 4) mt = 4;               // LDS: 16 waves x MT x 1 KiB x 4
     {
@@ -429,57 +638,63 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             if (pe != hipErrorNotSupported) return pe;
         }
     }
-    // n-tiles per workgroup (NORM forms).  Every workgroup re-reads its rows of the activation operand, so at 64 rows the
-    // activations cost as much L2 -> CU traffic as the weights (in-kernel stamps, tools/gemm_clk.hip: the wait for the first
-    // operand tile was 4.2 us against 2.1 us with that traffic removed).  More n-tiles per workgroup divide it, as long as the
-    // grid stays wide enough: measured at 64 rows, qkv 768 -> 192 workgroups -0.95 us, gate/up 512 -> 256 -0.85 us; the
-    // 16-wave form loses (its reduction grows).  A weight whose last tile is partial (the speech head: 513 tiles) takes part
-    // when its packed buffer was padded to a multiple of the tile group (GemmArgs::packed_tiles).
-    int nt = epi == EPI_SILU ? 2 : 1;
-    if (norm && epi != EPI_F32 && (!a.row_index || a.packed_tiles > 0)) {
-        static int force = -1;
-        if (force < 0) { const char* e = getenv("T3_GEMM_NT"); force = e ? atoi(e) : 0; }
-        const int ntiles = a.packed_tiles > 0 ? a.packed_tiles : (a.N + 15) / 16 * (epi == EPI_SILU ? 2 : 1);      // packed weight tiles
-        const int groups = ((a.M + 15) / 16 + mt - 1) / mt;
-        const int want = epi == EPI_SILU ? 256 : 192;
-        for (int c = 4; c > nt; c >>= 1)
-            if (ntiles % c == 0 && (long)(ntiles / c) * groups >= want) { nt = c; break; }
-        if (force == 1 || force == 2 || force == 4) nt = epi == EPI_SILU ? (force < 2 ? 2 : force) : force;
-        if (ntiles % nt) nt = epi == EPI_SILU ? 2 : 1;
+    if (norm) {
+        // n-tiles per workgroup.  Every workgroup re-reads its rows of the activation operand, so more n-tiles per workgroup divide
+        // that traffic, as long as the grid still covers the chip: the largest tile group that leaves >= 256 workgroups (one per
+        // CU: qkv at 64 rows takes groups of 3 = 256 workgroups rather than groups of 4 = 192), else the largest that leaves >= 192
+        // (256 for gate/up).  A weight whose last tile is partial (the speech head: 513 tiles) takes part when its packed buffer
+        // was padded to a multiple of the tile group (GemmArgs::packed_tiles).
+        if (mt > 2) mt = 2;
+        int nt = epi == EPI_SILU ? 2 : 1;
+        if (epi != EPI_F32 && (!a.row_index || a.packed_tiles > 0)) {
+            static int force = -1;
+            if (force < 0) { const char* e = getenv("T3_GEMM_NT"); force = e ? atoi(e) : 0; }
+            const int ntiles = a.packed_tiles > 0 ? a.packed_tiles : (a.N + 15) / 16 * (epi == EPI_SILU ? 2 : 1);      // packed weight tiles
+            const int groups = ((a.M + 15) / 16 + mt - 1) / mt;
+            const int want = epi == EPI_SILU ? 256 : 192;
+            int pick = 0;
+            for (int c = 4; c > nt && !pick; --c)
+                if ((epi != EPI_SILU || c % 2 == 0) && ntiles % c == 0 && (long)(ntiles / c) * groups >= 256) pick = c;
+            for (int c = 4; c > nt && !pick; --c)
+                if ((epi != EPI_SILU || c % 2 == 0) && ntiles % c == 0 && (long)(ntiles / c) * groups >= want) pick = c;
+            if (pick) nt = pick;
+            if (force >= 1 && force <= 4 && (epi != EPI_SILU || force % 2 == 0) && ntiles % force == 0) nt = force;
+        }
+        return launch_gemm2_norm(&a, epi, mt, nt, s);
     }
-#define T3_MT(E, NT, NWV, NRM)                                               \
+    if (nw == 16 && mt == 1 && (a.K == D || a.K == F) && a.N % 16 == 0 && !a.row_index && (epi == EPI_F32 || epi == EPI_RESID))
+        return launch_gemm2_16(&a, epi, a.K / 512, s);
+#define T3_MT(E, NT, NWV)                                                    \
     switch (mt) {                                                            \
-        case 1: return launch_gemm_t<1, NT, E, NWV, NRM>(a, s);              \
-        case 2: return launch_gemm_t<2, NT, E, NWV, NRM>(a, s);              \
-        case 4: return launch_gemm_t<(NT == 4 ? 2 : 4), NT, E, NWV, NRM>(a, s);              \
-        default: return launch_gemm_t<(NWV == 16 ? 4 : (NT == 4 ? 2 : 8 / NT)), NT, E, NWV, NRM>(a, s); \
+        case 1: return launch_gemm_t<1, NT, E, NWV>(a, s);                   \
+        case 2: return launch_gemm_t<2, NT, E, NWV>(a, s);                   \
+        case 4: return launch_gemm_t<4, NT, E, NWV>(a, s);                   \
+        default: return launch_gemm_t<(NWV == 16 ? 4 : 8 / NT), NT, E, NWV>(a, s); \
     }
     if (nw == 16) {
-        if (norm) return hipErrorInvalidValue;
         switch (epi) {
-            case EPI_F32: T3_MT(EPI_F32, 1, 16, false)
-            case EPI_RESID: T3_MT(EPI_RESID, 1, 16, false)
-            default: return hipErrorInvalidValue;
-        }
-    }
-    if (norm) {
-        switch (epi) {
-            case EPI_F32: T3_MT(EPI_F32, 1, 4, true)
-            case EPI_BF16:
-                if (nt == 4) { T3_MT(EPI_BF16, 4, 4, true) } else if (nt == 2) { T3_MT(EPI_BF16, 2, 4, true) } else { T3_MT(EPI_BF16, 1, 4, true) }
-            case EPI_SILU:
-                if (nt == 4) { T3_MT(EPI_SILU, 4, 4, true) } else { T3_MT(EPI_SILU, 2, 4, true) }
+            case EPI_F32: T3_MT(EPI_F32, 1, 16)
+            case EPI_RESID: T3_MT(EPI_RESID, 1, 16)
             default: return hipErrorInvalidValue;
         }
     }
     switch (epi) {
-        case EPI_F32: T3_MT(EPI_F32, 1, 4, false)
-        case EPI_BF16: T3_MT(EPI_BF16, 1, 4, false)
-        case EPI_RESID: T3_MT(EPI_RESID, 1, 4, false)
-        case EPI_SILU: T3_MT(EPI_SILU, 2, 4, false)
+        case EPI_F32: T3_MT(EPI_F32, 1, 4)
+        case EPI_BF16: T3_MT(EPI_BF16, 1, 4)
+        case EPI_RESID: T3_MT(EPI_RESID, 1, 4)
+        case EPI_SILU: T3_MT(EPI_SILU, 2, 4)
     }
 #undef T3_MT
     return hipErrorInvalidValue;
+}
+
+// W'[n][k] = bf16(W[n][k] * ln[k]): the load-time fold of an RMSNorm weight into the projection that consumes its output
+// (contract: DESIGN.md "RMSNorm"; the checker's fold_ln is the same arithmetic).
+void fold_norm_weight(const uint16_t* W, int N, int K, const uint16_t* ln, uint16_t* out) {
+    auto b2f = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    auto f2b = [](float f) { uint32_t u; memcpy(&u, &f, 4); if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) out[(size_t)n * K + k] = f2b(b2f(W[(size_t)n * K + k]) * b2f(ln[k]));
 }
 
 void pack_weight(const uint16_t* W, int N, int K, int Npad, uint16_t* out) {
@@ -806,8 +1021,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
 }
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
-    static int nw = 0, nt = 0;
-    if (!nw) { const char* e = getenv("T3_ATTN_WAVES"); nw = e ? atoi(e) : 4; const char* t = getenv("T3_ATTN_NT"); nt = t ? atoi(t) : 1; }
+    static int nw_env = -1, nt = 0;
+    if (nw_env < 0) { const char* e = getenv("T3_ATTN_WAVES"); nw_env = e ? atoi(e) : 0; const char* t = getenv("T3_ATTN_NT"); nt = t ? atoi(t) : 1; }
+    // 4 waves per (row, head) fill the chip from 16 rows on (16 heads x 16 rows x 4 waves = 4 waves per CU); below that the
+    // launch is latency-bound and 8 waves halve the number of sequential 64-token chunks per wave (B = 1: 2 rows -> 32 workgroups)
+    const int nw = nw_env == 4 || nw_env == 8 ? nw_env : (a.rows <= 8 ? 8 : 4);
     const dim3 grid(H, a.rows);
     const bool fuse = a.qkv != nullptr;
     const size_t lds = ((size_t)a.max_chunks * 66 + (size_t)(nw == 8 ? 8 : 4) * 96) * sizeof(float);
@@ -1126,6 +1344,7 @@ hipError_t prepare_kernels() {
     if (done) return hipSuccess;
     const size_t lds = (size_t)(SLOTS + 8 + 256) * sizeof(unsigned long long);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = prepare_gemm2();
     if (e == hipSuccess) done = true;
     return e;
 }

@@ -110,9 +110,14 @@ class LLM:
         self.max_model_len, self.seed = int(max_model_len), int(seed)
         if device_id is None:
             device_id = int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.device_count() > 1 else 0
+        # enforce_eager: in vLLM it switches off CUDA-graph capture and torch.compile (start-up time and memory knobs; the
+        # reference server always passes True, api_server.py:157 -> tts.py:156,163).  Here a decode step is replayed from a
+        # hipGraph captured on first use -- no compile step, a few MB -- and token ids do not depend on it, so the flag is
+        # accepted and NOT applied unless T3_HONOR_ENFORCE_EAGER=1 asks for launch-by-launch steps (debugging, profiling).
+        eager = bool(enforce_eager) and os.environ.get("T3_HONOR_ENFORCE_EAGER", "0") == "1"
         self.engine = T3Engine(n_layers=n_layers, text_vocab=text_vocab, max_model_len=max_model_len, max_seqs=max_num_seqs,
                                device_id=device_id, kv_bytes=kv_cache_bytes, gpu_memory_utilization=gpu_memory_utilization,
-                               enforce_eager=enforce_eager, debug_logits=debug_logits, max_batched_rows=max_num_batched_tokens)
+                               enforce_eager=eager, debug_logits=debug_logits, max_batched_rows=max_num_batched_tokens)
         ckpt = os.path.join(model, "model.safetensors") if model and os.path.isdir(model) else model
         if load_format == "dummy" or not (ckpt and os.path.exists(ckpt)):
             if load_format != "dummy":

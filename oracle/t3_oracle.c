@@ -223,44 +223,41 @@ void orc_gemm_w(const uint16_t* x, const OrcW* W, int M, float* out, int seg_len
         }
 }
 
-/* RMSNorm folded into the consuming GEMM (DESIGN.md "RMSNorm"):  y = rstd[m] * GEMM(bf16(h (.) w), W).
- * Row statistic, in the order the GEMM waves see the operand: segment s = k / 256 (one wave), lane group
- * q = (k % 32) / 8; p_q = sequential h*h adds over kb = 0..7 (k = 256 s + 32 kb + 8 q + j, j = 0..7 inner);
- * S_s = (p_0 + p_1) + (p_2 + p_3);  ss = ((S_0 + S_1) + S_2) + S_3;  rstd = 1 / sqrt(ss / 1024 + eps).   */
+/* RMSNorm folded into the consuming GEMM (DESIGN.md "RMSNorm"):  y = rstd[m] * GEMM(h, W'),  W'[n][k] = bf16(W[n][k] * w_ln[k])
+ * (the norm weight is folded into the projection matrix ONCE, when the weights are loaded; the activations go to the matrix
+ * cores untouched).  Row statistic, on the matrix cores as well: segment s = k / 256 (one wave of the GPU workgroup) folds
+ * S_s = sum_k h_k * h_k over its 256 k with the SAME MFMA chain as a GEMM segment (blocks of 8 k ascending from +0: the wave
+ * multiplies its A fragment with itself and reads the diagonal);  ss = ((S_0 + S_1) + S_2) + S_3;  rstd = 1 / sqrt(ss / 1024 + eps). */
 void orc_row_rstd(const uint16_t* h, int rows, float* rstd) {
     for (int r = 0; r < rows; ++r) {
         const uint16_t* x = h + (size_t)r * T3_D;
         float S[4];
-        for (int s = 0; s < 4; ++s) {
-            float p[4];
-            for (int q = 0; q < 4; ++q) {
-                float a = 0.0f;
-                for (int kb = 0; kb < 8; ++kb)
-                    for (int j = 0; j < 8; ++j) { const float v = bf2f(x[256 * s + 32 * kb + 8 * q + j]); a = fmaf(v, v, a); }
-                p[q] = a;
-            }
-            S[s] = (p[0] + p[1]) + (p[2] + p[3]);
-        }
+        for (int s = 0; s < 4; ++s) S[s] = orc_mfma_bf16_dot(x + 256 * s, x + 256 * s, 256, 0.0f);
         const float ss = ((S[0] + S[1]) + S[2]) + S[3];
         rstd[r] = 1.0f / sqrtf(ss * (1.0f / 1024.0f) + T3_EPS);
     }
 }
-/* out[m][n] = rstd[m] * GEMM(bf16(h[m][k] * w[k]), W)   (K = 1024, segments of 256) */
-void orc_norm_gemm_w(const uint16_t* h, const uint16_t* w, const OrcW* W, int M, float* out) {
-    uint16_t* xw = (uint16_t*)malloc((size_t)M * T3_D * 2);
+/* W' = bf16(W (.) w) row by row: the load-time fold of an RMSNorm weight into the projection that consumes it */
+static uint16_t* fold_ln(const uint16_t* W /* [N][1024] */, int N, const uint16_t* w) {
+    uint16_t* out = (uint16_t*)malloc((size_t)N * T3_D * 2);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < T3_D; ++k) out[(size_t)n * T3_D + k] = f2bf(bf2f(W[(size_t)n * T3_D + k]) * bf2f(w[k]));
+    return out;
+}
+/* out[m][n] = rstd[m] * GEMM(h, W')   (K = 1024, segments of 256; W' already carries the norm weight) */
+void orc_norm_gemm_w(const uint16_t* h, const OrcW* Wf, int M, float* out) {
     float* rstd = (float*)malloc(sizeof(float) * M);
-    for (int m = 0; m < M; ++m)
-        for (int k = 0; k < T3_D; ++k) xw[(size_t)m * T3_D + k] = f2bf(bf2f(h[(size_t)m * T3_D + k]) * bf2f(w[k]));
     orc_row_rstd(h, M, rstd);
-    orc_gemm_w(xw, W, M, out, 256);
+    orc_gemm_w(h, Wf, M, out, 256);
     for (int m = 0; m < M; ++m)
-        for (int n = 0; n < W->N; ++n) out[(size_t)m * W->N + n] = out[(size_t)m * W->N + n] * rstd[m];
-    free(xw); free(rstd);
+        for (int n = 0; n < Wf->N; ++n) out[(size_t)m * Wf->N + n] = out[(size_t)m * Wf->N + n] * rstd[m];
+    free(rstd);
 }
 void orc_norm_gemm_nk(const uint16_t* h, const uint16_t* w, const uint16_t* Wn, int M, int N, float* out) {
-    OrcW W = orcw_make(Wn, N, T3_D);
-    orc_norm_gemm_w(h, w, &W, M, out);
-    orcw_free(&W);
+    uint16_t* f = fold_ln(Wn, N, w);
+    OrcW W = orcw_make(f, N, T3_D);
+    orc_norm_gemm_w(h, &W, M, out);
+    orcw_free(&W); free(f);
 }
 
 /* Helper for tests: W given in its natural [N][K] layout. */
@@ -386,14 +383,15 @@ typedef struct {
     OrcW wo;            /* N = 1024 */
     OrcW wgu;           /* N = 8192: gate(0..4095) up(4096..8191) */
     OrcW wd;            /* K = 4096, N = 1024 */
-    uint16_t *sq, *sk, *sv, *sg, *su;   /* staging of the natural-layout parts until all have arrived */
+    uint16_t *sq, *sk, *sv, *sg, *su;   /* staging of the natural-layout parts until all have arrived (and the norm weight that is folded in) */
     uint16_t *ln1, *ln2;/* [1024] */
 } OrcLayer;
 
 typedef struct {
     int n_layers, text_vocab, max_pos;
     OrcLayer* layers;
-    uint16_t *norm, *text_emb, *speech_emb, *text_pos, *speech_pos; OrcW head /* N = 8194 */;
+    uint16_t *norm, *text_emb, *speech_emb, *text_pos, *speech_pos; OrcW head /* N = 8194, final norm weight folded in */;
+    uint16_t* head_raw;
     float *cos_t, *sin_t;
     /* KV cache: [stream][layer][pos][2][1024] bf16 */
     int n_streams; uint16_t* kv;
@@ -412,12 +410,33 @@ OrcModel* orc_create(int n_layers, int text_vocab, int max_pos, int n_streams) {
 
 static uint16_t* dup(const uint16_t* W, size_t n) { uint16_t* t = (uint16_t*)malloc(n * 2); memcpy(t, W, n * 2); return t; }
 
-/* concatenate natural-layout [rows_i][K] parts along N and decode */
-static OrcW orcw_concat(const uint16_t* const* parts, const int* rows, int nparts, int K) {
+/* concatenate natural-layout [rows_i][1024] parts along N, fold the norm weight in, decode */
+static OrcW orcw_concat_folded(const uint16_t* const* parts, const int* rows, int nparts, const uint16_t* ln) {
     int N = 0; for (int i = 0; i < nparts; ++i) N += rows[i];
-    uint16_t* all = (uint16_t*)malloc((size_t)N * K * 2); size_t off = 0;
-    for (int i = 0; i < nparts; ++i) { memcpy(all + off, parts[i], (size_t)rows[i] * K * 2); off += (size_t)rows[i] * K; }
-    OrcW w = orcw_make(all, N, K); free(all); return w;
+    uint16_t* all = (uint16_t*)malloc((size_t)N * T3_D * 2); size_t off = 0;
+    for (int i = 0; i < nparts; ++i) { memcpy(all + off, parts[i], (size_t)rows[i] * T3_D * 2); off += (size_t)rows[i] * T3_D; }
+    uint16_t* f = fold_ln(all, N, ln);
+    OrcW w = orcw_make(f, N, T3_D); free(all); free(f); return w;
+}
+/* build the folded matrices of a layer / the head as soon as their parts and their norm weight are all present */
+static void orc_try_fold(OrcModel* m, int L) {
+    if (L >= 0) {
+        OrcLayer* y = &m->layers[L];
+        if (y->sq && y->sk && y->sv && y->ln1 && !y->wqkv.e) {
+            const uint16_t* p[3] = {y->sq, y->sk, y->sv}; const int r[3] = {T3_D, T3_D, T3_D};
+            y->wqkv = orcw_concat_folded(p, r, 3, y->ln1);
+            free(y->sq); free(y->sk); free(y->sv); y->sq = y->sk = y->sv = NULL;
+        }
+        if (y->sg && y->su && y->ln2 && !y->wgu.e) {
+            const uint16_t* p[2] = {y->sg, y->su}; const int r[2] = {T3_F, T3_F};
+            y->wgu = orcw_concat_folded(p, r, 2, y->ln2);
+            free(y->sg); free(y->su); y->sg = y->su = NULL;
+        }
+    } else if (m->head_raw && m->norm && !m->head.e) {
+        const uint16_t* p[1] = {m->head_raw}; const int r[1] = {T3_V};
+        m->head = orcw_concat_folded(p, r, 1, m->norm);
+        free(m->head_raw); m->head_raw = NULL;
+    }
 }
 
 /* Tensor names follow the checkpoint (t3.py:300-332, tts.py:112-137): "tfmr.layers.N.self_attn.q_proj.weight" ...
@@ -433,32 +452,19 @@ int orc_set_tensor(OrcModel* m, const char* name, const uint16_t* data, int rows
         else if (!strcmp(rest, "self_attn.v_proj.weight")) slot = &y->sv;
         else if (!strcmp(rest, "mlp.gate_proj.weight")) slot = &y->sg;
         else if (!strcmp(rest, "mlp.up_proj.weight")) slot = &y->su;
-        if (slot) {
-            free(*slot); *slot = dup(data, (size_t)rows * cols);
-            if (y->sq && y->sk && y->sv && !y->wqkv.e) {
-                const uint16_t* p[3] = {y->sq, y->sk, y->sv}; const int r[3] = {T3_D, T3_D, T3_D};
-                y->wqkv = orcw_concat(p, r, 3, T3_D);
-                free(y->sq); free(y->sk); free(y->sv); y->sq = y->sk = y->sv = NULL;
-            }
-            if (y->sg && y->su && !y->wgu.e) {
-                const uint16_t* p[2] = {y->sg, y->su}; const int r[2] = {T3_F, T3_F};
-                y->wgu = orcw_concat(p, r, 2, T3_D);
-                free(y->sg); free(y->su); y->sg = y->su = NULL;
-            }
-            return 0;
-        }
+        if (slot) { free(*slot); *slot = dup(data, (size_t)rows * cols); orc_try_fold(m, L); return 0; }
         if (!strcmp(rest, "self_attn.o_proj.weight")) { y->wo = orcw_make(data, rows, cols); return 0; }
         if (!strcmp(rest, "mlp.down_proj.weight")) { y->wd = orcw_make(data, rows, cols); return 0; }
-        if (!strcmp(rest, "input_layernorm.weight")) { y->ln1 = dup(data, T3_D); return 0; }
-        if (!strcmp(rest, "post_attention_layernorm.weight")) { y->ln2 = dup(data, T3_D); return 0; }
+        if (!strcmp(rest, "input_layernorm.weight")) { y->ln1 = dup(data, T3_D); orc_try_fold(m, L); return 0; }
+        if (!strcmp(rest, "post_attention_layernorm.weight")) { y->ln2 = dup(data, T3_D); orc_try_fold(m, L); return 0; }
         return -1;
     }
-    if (!strcmp(name, "tfmr.norm.weight")) { m->norm = dup(data, T3_D); return 0; }
+    if (!strcmp(name, "tfmr.norm.weight")) { m->norm = dup(data, T3_D); orc_try_fold(m, -1); return 0; }
     if (!strcmp(name, "text_emb.weight")) { m->text_emb = dup(data, (size_t)rows * cols); return 0; }
     if (!strcmp(name, "speech_emb.weight")) { m->speech_emb = dup(data, (size_t)rows * cols); return 0; }
     if (!strcmp(name, "text_pos_emb.emb.weight")) { m->text_pos = dup(data, (size_t)rows * cols); return 0; }
     if (!strcmp(name, "speech_pos_emb.emb.weight")) { m->speech_pos = dup(data, (size_t)rows * cols); return 0; }
-    if (!strcmp(name, "speech_head.weight")) { m->head = orcw_make(data, rows, cols); return 0; }
+    if (!strcmp(name, "speech_head.weight")) { m->head_raw = dup(data, (size_t)rows * cols); orc_try_fold(m, -1); return 0; }
     return -1;
 }
 
@@ -468,7 +474,7 @@ void orc_destroy(OrcModel* m) {
         orcw_free(&y->wqkv); orcw_free(&y->wo); orcw_free(&y->wgu); orcw_free(&y->wd);
         free(y->sq); free(y->sk); free(y->sv); free(y->sg); free(y->su); free(y->ln1); free(y->ln2);
     }
-    orcw_free(&m->head);
+    orcw_free(&m->head); free(m->head_raw);
     free(m->layers); free(m->norm); free(m->text_emb); free(m->speech_emb); free(m->text_pos);
     free(m->speech_pos); free(m->cos_t); free(m->sin_t); free(m->kv); free(m);
 }
@@ -490,7 +496,7 @@ void orc_forward_rows(OrcModel* m, uint16_t* h, const int* row_stream, const int
     for (int L = 0; L < m->n_layers; ++L) {
         if (tap_layer == L && tap) memcpy(tap, h, (size_t)rows * T3_D * 2);
         OrcLayer* y = &m->layers[L];
-        orc_norm_gemm_w(h, y->ln1, &y->wqkv, rows, f);
+        orc_norm_gemm_w(h, &y->wqkv, rows, f);
         for (size_t i = 0; i < (size_t)rows * 3072; ++i) qkv[i] = f2bf(f[i]);
         for (int r = 0; r < rows; ++r) {
             uint16_t* q = qkv + (size_t)r * 3072;
@@ -508,7 +514,7 @@ void orc_forward_rows(OrcModel* m, uint16_t* h, const int* row_stream, const int
             }
         orc_gemm_w(att, &y->wo, rows, f, 64);
         for (size_t i = 0; i < (size_t)rows * T3_D; ++i) h[i] = f2bf(bf2f(h[i]) + rbf(f[i]));
-        orc_norm_gemm_w(h, y->ln2, &y->wgu, rows, f);
+        orc_norm_gemm_w(h, &y->wgu, rows, f);
         for (int r = 0; r < rows; ++r)
             for (int i = 0; i < T3_F; ++i)
                 act[(size_t)r * T3_F + i] = silu_mul(f2bf(f[(size_t)r * 8192 + i]), f2bf(f[(size_t)r * 8192 + 4096 + i]));
@@ -527,7 +533,7 @@ void orc_cfg_logits(OrcModel* m, const uint16_t* hc, const uint16_t* hu, float c
     uint16_t x[2 * T3_D];
     memcpy(x, hc, T3_D * 2); memcpy(x + T3_D, hu, T3_D * 2);
     float* f = (float*)malloc(sizeof(float) * 2 * T3_V);
-    orc_norm_gemm_w(x, m->norm, &m->head, 2, f);
+    orc_norm_gemm_w(x, &m->head, 2, f);
     for (int v = 0; v < T3_V; ++v) {
         const float lc = rbf(f[v]), lu = rbf(f[T3_V + v]);
         const float d = rbf(lc - lu);

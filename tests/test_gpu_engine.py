@@ -263,7 +263,7 @@ def test_llm_surface(E, oracle, tiny_oracle, cond, tmp_path):
     mm = {"conditionals": [cond]}
     # (1) committed goldens (C1 prompt, 2 layers): greedy, and the reference's sampling defaults with an explicit seed
     c1 = {"prompt_token_ids": tokj["en_english_ids"], "multi_modal_data": mm}
-    r = llm.generate([c1], SamplingParams(temperature=0.0, max_tokens=64, ignore_eos=True))
+    r = llm.generate([c1], SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=64, ignore_eos=True))     # the golden's penalty (tts.py:416)
     assert [t - 2500 for t in r[0].outputs[0].token_ids] == z["l2_en_greedy_ids"].tolist()
     sp_seeded = SamplingParams(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, max_tokens=64, ignore_eos=True)
     r = llm.generate([c1], sp_seeded)
@@ -346,7 +346,7 @@ def test_real_checkpoint_path_safetensors(E, cond, tmp_path):
     llm = LLM(model=str(mdir), task="generate", tokenizer="EnTokenizer", tokenizer_mode="custom", gpu_memory_utilization=0.2,
               enforce_eager=True, max_model_len=400, max_num_seqs=2, num_hidden_layers=2)
     r = llm.generate([{"prompt_token_ids": tokj["en_english_ids"], "multi_modal_data": {"conditionals": [cond]}}],
-                     SamplingParams(temperature=0.0, max_tokens=64, ignore_eos=True))
+                     SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=64, ignore_eos=True))
     assert [t - 2500 for t in r[0].outputs[0].token_ids] == z["l2_en_greedy_ids"].tolist()
     llm.shutdown()
     with pytest.raises(ValueError):

@@ -129,3 +129,21 @@ def test_c4_continuous_batching_full_size(ctx):
         eng.release(i)
     assert checked == 6
     eng.close()
+
+
+def test_c2_b1_through_llm_as_the_server_drives_it(ctx):
+    """C2 (BASELINE.json configs[1]): English vocabulary, B = 1, max_model_len = 400, 30 layers, through the vLLM-shaped surface with
+    the flags the unchanged server passes (enforce_eager=True, api_server.py:157): graph replay is used regardless (llm.py), and the
+    292-token utterance starts with the committed 30-layer oracle stream."""
+    from chatterbox_vllm2_amd import LLM, SamplingParams
+    llm = LLM(model="./t3-model", task="generate", tokenizer="EnTokenizer", tokenizer_mode="custom", gpu_memory_utilization=0.2,
+              enforce_eager=True, max_model_len=400, max_num_seqs=1, load_format="dummy")
+    assert llm.engine.cfg.enforce_eager == 0
+    p = ctx["tok"]["en_english_ids"]
+    assert len(ctx["asm"](p)) == 108
+    r = llm.generate([{"prompt_token_ids": p, "multi_modal_data": {"conditionals": [ctx["cond"]]}}],
+                     SamplingParams(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, max_tokens=400 - 108, ignore_eos=True))
+    ids = [t - 2500 for t in r[0].outputs[0].token_ids]
+    want = ctx["z"]["l30_en_sampled_ids"].tolist()
+    assert len(ids) == 292 and ids[:len(want)] == want and r[0].outputs[0].finish_reason == "length"
+    llm.shutdown()

@@ -120,7 +120,10 @@ def test_logits_tolerance_vs_hf_fp32_30_layers(oracle):
     from transformers import DynamicCache
     from chatterbox_vllm2_amd.weights import synthetic_cond_emb, synthetic_tensors
     NL, N = 30, 24
-    tens = list(synthetic_tensors(NL, 704, 1234)); w = dict(tens)
+    g = torch.Generator().manual_seed(77)          # the synthetic checkpoint has unit norm weights: give every RMSNorm a real one, so that
+    tens = [(k, (1.0 + 0.25 * torch.randn(v.shape, generator=g)).to(torch.bfloat16) if "norm" in k else v)      # the load-time fold W' = bf16(W * w_ln) is exercised
+            for k, v in synthetic_tensors(NL, 704, 1234)]
+    w = dict(tens)
     m = oracle.OracleModel(NL, 704, max_pos=128).load(tens)
     prompt = make_prompt(22, seed=5); cond = synthetic_cond_emb(1)
     ids, lg = m.generate(prompt, cond, oracle.make_sampling(temperature=0.0, repetition_penalty=1.0, max_tokens=N, ignore_eos=True),

@@ -1,4 +1,5 @@
-// Persistent layer-chain kernel of the T3 decode engine for gfx950 (MI355X): the four dependent projections between two
+// DIAGNOSTIC (built by tools/chain_proto.hip only; not part of libt3engine.so -- measured slower than the launches it would replace,
+// DESIGN.md section 8).  Persistent layer-chain kernel of the T3 decode engine for gfx950 (MI355X): the four dependent projections between two
 // attention calls -- o_proj(+residual) -> gate/up(RMSNorm folded, SiLU*mul) -> down_proj(+residual) -> the NEXT layer's qkv
 // (RMSNorm folded) -- in ONE launch of 256 workgroups (one per CU) instead of four launches.
 //
@@ -26,10 +27,23 @@
 //     reports the step as failed); it never hangs the GPU.
 // Placement-independent: nothing depends on which XCD a workgroup lands on; `blockIdx % 8` only groups the workgroups that
 // share a weight tile so that they share an L2 (speed).
-#include "t3_device.h"
-#include "t3_kernels.h"
+#include "../chatterbox-vllm2_amd/csrc/t3_device.h"
+#include "../chatterbox-vllm2_amd/csrc/t3_kernels.h"
 
 namespace t3 {
+
+constexpr int CHAIN_WGS = 256;                    // one workgroup per CU
+struct ChainArgs {
+    const uint4 *Wo, *Wgu, *Wd, *Wqkv;            // packed weights of this layer (gate/up and qkv with their norm weights folded in); Wqkv = the NEXT layer's
+    const uint16_t* att;                          // [M][1024] attention output (previous launch)
+    uint16_t* h;                                  // [M][1024] residual stream, updated in place
+    uint16_t* act;                                // [M][4096] scratch
+    uint16_t* qkv;                                // [M][3072] out
+    int M;                                        // rows, <= 64
+    int phases;                                   // bit 0 o, bit 1 gate/up, bit 2 down, bit 3 qkv (executed in this order)
+    unsigned* flags;                              // [CHAIN_WGS] barrier epochs, zeroed once at allocation, never reset
+    unsigned* err;                                // set to 1 when a barrier wait gave up
+};
 
 typedef unsigned int cu32x4 __attribute__((ext_vector_type(4)));
 constexpr int AUX_SC1 = 16;                      // cache-policy bits of the raw buffer builtins on gfx94x/gfx950: sc0 = 1, nt = 2, sc1 = 16
@@ -68,7 +82,7 @@ struct ChainItem {
     // wbase = packed weights of the item's first n-tile at this wave's first k-block, + lane.  X: A operand [rows][32 KB] bf16.
     // out: [rows][ldo] bf16; ot0 = index of the item's first output tile (column ot0 * 16).  red: LDS scratch (RED_FLOATS).
     __device__ static __forceinline__ void run(uint4 (&wr)[16], const uint4* wbase, int KB, __amdgpu_buffer_rsrc_t xr_, int M, int mt0,
-                                               const uint16_t* ln_w, __amdgpu_buffer_rsrc_t or_, int ldo, int ot0, float* red) {
+                                               __amdgpu_buffer_rsrc_t or_, int ldo, int ot0, float* red) {
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int c = lane & 15, q = lane >> 4;
         const int K = KB * 32, k0 = wave * KBS * 32;
@@ -79,13 +93,11 @@ struct ChainItem {
             m = m < M ? m : M - 1;                  // padded rows re-read the last row; their outputs are dropped
             xoff[i] = (unsigned)(((size_t)m * K + k0 + q * 8) * 2);
         }
-        const uint4* lnp = NORM ? reinterpret_cast<const uint4*>(ln_w + k0 + q * 8) : nullptr;
-        uint4 xr[PDK][MT], lr[PDK];
+        uint4 xr[PDK][MT];
 #pragma unroll
         for (int j = 0; j < PDK; ++j) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) xr[j][i] = ld_sc1(xr_, xoff[i] + j * 64);
-            if (NORM) lr[j] = lnp[j * 4];
         }
         // residual operand of this thread's output pieces: requested now, consumed in the epilogue
         uint4 hres[PITER];
@@ -98,11 +110,10 @@ struct ChainItem {
                 hres[k] = (p < PIECES && m < M) ? ld_sc1(or_, (unsigned)(((size_t)m * ldo + n) * 2)) : make_uint4(0, 0, 0, 0);
             }
         }
-        f32x4 acc[MT][NT], P[MT][NT];
-        float ssq[MT];
+        f32x4 acc[MT][NT], P[MT][NT], ssq[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            ssq[i] = 0.0f;
+            ssq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < NT; ++t) { acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; P[i][t] = acc[i][t]; }
         }
@@ -111,17 +122,8 @@ struct ChainItem {
             for (int j = 0; j < PDK; ++j) {
                 const int kb = kbase + j;
                 if constexpr (NORM) {
-                    float lw[8]; unpack8(lr[j], lw);
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        float xf[8]; unpack8(xr[j][i], xf);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ssq[i] = __builtin_fmaf(xf[e], xf[e], ssq[i]);
-                        uint4 o;
-                        o.x = cvt_pk(xf[0] * lw[0], xf[1] * lw[1]); o.y = cvt_pk(xf[2] * lw[2], xf[3] * lw[3]);
-                        o.z = cvt_pk(xf[4] * lw[4], xf[5] * lw[5]); o.w = cvt_pk(xf[6] * lw[6], xf[7] * lw[7]);
-                        xr[j][i] = o;
-                    }
+                    for (int i = 0; i < MT; ++i) ssq[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(xr[j][i]), as_frag(xr[j][i]), ssq[i], 0, 0, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -142,7 +144,6 @@ struct ChainItem {
                     for (int t = 0; t < NT; ++t) wr[j * NT + t] = ld_nt(wbase + (size_t)t * KB * 64 + (kb + PDK) * 64);
 #pragma unroll
                     for (int i = 0; i < MT; ++i) xr[j][i] = ld_sc1(xr_, xoff[i] + (kb + PDK) * 64);
-                    if (NORM) lr[j] = lnp[(kb + PDK) * 4];
                 }
             }
         }
@@ -157,9 +158,9 @@ struct ChainItem {
         if constexpr (NORM) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                float v = ssq[i];
-                v = v + __shfl_xor(v, 16); v = v + __shfl_xor(v, 32);
-                if (q == 0) rowsum[wave * (MT * 16) + i * 16 + c] = v;
+                const int r = c & 3;
+                const float d = r == 0 ? ssq[i][0] : r == 1 ? ssq[i][1] : r == 2 ? ssq[i][2] : ssq[i][3];
+                if ((c >> 2) == q) rowsum[wave * (MT * 16) + i * 16 + c] = d;      // diagonal of the A fragment times itself
             }
         }
         __syncthreads();                              // B1 (the sync wave joins it)
@@ -226,9 +227,12 @@ __device__ __forceinline__ void chain_grid_barrier(unsigned* flags, unsigned tar
         const cu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(fr, lane * 16, 0, AUX_SC1);
         const bool ok = (int)(v.x - target) >= 0 && (int)(v.y - target) >= 0 && (int)(v.z - target) >= 0 && (int)(v.w - target) >= 0;
         if (__all(ok)) break;
-        if (spins > (1u << 21)) {                 // ~seconds: another workgroup never arrived (not resident?).  Give up, loudly.
-            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
+        // Bounded: ~0.3 s without every workgroup arriving (one of them not resident?) -> give up, loudly, and let every later
+        // wait of this and the following launches fall through at once (the engine reports the step as failed and stops).
+        if ((spins & 255u) == 255u) {
+            const unsigned e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (e != 0u) break;
+            if (spins >= (1u << 18)) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
         __builtin_amdgcn_s_sleep(2);
     }
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(320) void chain_kernel(ChainArgs a) {
     else if (do_q) { if (it_q) ItemQ::prefetch(wr, w_q, KB1); }
 
     if (do_o) {
-        if (it_od) ItemO::run(wr, w_o, KB1, r_att, a.M, od_mt, nullptr, r_h, D, od_nt, red);
+        if (it_od) ItemO::run(wr, w_o, KB1, r_att, a.M, od_mt, r_h, D, od_nt, red);
         drain_and_sync();
         if (do_gu) ItemGU::prefetch(wr, w_gu, KB1);
         else if (do_dn) { if (it_od) ItemD::prefetch(wr, w_d, KB4); }
@@ -312,20 +316,20 @@ __global__ __launch_bounds__(320) void chain_kernel(ChainArgs a) {
         __syncthreads();                                          // B3
     }
     if (do_gu) {
-        ItemGU::run(wr, w_gu, KB1, r_h, a.M, gu_mt0, a.ln2, r_act, F, gu_pg * GU_PAIRS, red);
+        ItemGU::run(wr, w_gu, KB1, r_h, a.M, gu_mt0, r_act, F, gu_pg * GU_PAIRS, red);
         drain_and_sync();
         if (do_dn) { if (it_od) ItemD::prefetch(wr, w_d, KB4); }
         else if (do_q) { if (it_q) ItemQ::prefetch(wr, w_q, KB1); }
         __syncthreads();
     }
     if (do_dn) {
-        if (it_od) ItemD::run(wr, w_d, KB4, r_act, a.M, od_mt, nullptr, r_h, D, od_nt, red);
+        if (it_od) ItemD::run(wr, w_d, KB4, r_act, a.M, od_mt, r_h, D, od_nt, red);
         drain_and_sync();
         if (do_q) { if (it_q) ItemQ::prefetch(wr, w_q, KB1); }
         __syncthreads();
     }
     if (do_q) {
-        if (it_q) ItemQ::run(wr, w_q, KB1, r_h, a.M, q_mt, a.ln1n, r_qkv, QKV, q_g * Q_NT, red);
+        if (it_q) ItemQ::run(wr, w_q, KB1, r_h, a.M, q_mt, r_qkv, QKV, q_g * Q_NT, red);
         drain_and_sync();
         __syncthreads();
     }
@@ -339,8 +343,19 @@ size_t chain_lds_bytes(int mtt) {
     return gu > q ? gu : q;
 }
 
+bool chain_supported() {
+    // the grid barrier needs all 256 workgroups resident at once: one per CU
+    static int ok = -1;
+    if (ok < 0) {
+        int dev = 0; hipDeviceProp_t p;
+        ok = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= CHAIN_WGS) ? 1 : 0;
+    }
+    return ok == 1;
+}
+
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.M > 64 || !a.phases) return hipErrorInvalidValue;
+    if (!chain_supported()) return hipErrorNotSupported;
     const int mtt = (a.M + 15) / 16;
     const size_t lds = chain_lds_bytes(mtt);
     switch (mtt) {

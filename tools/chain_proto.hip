@@ -4,7 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt tools/chain_proto.hip -o tools/chain_proto
 // args: rows (default 64), repeats (default 20)
 #include "../chatterbox-vllm2_amd/csrc/t3_kernels.hip"
-#include "../chatterbox-vllm2_amd/csrc/chain_kernel.hip"
+#include "chain_kernel.hip"
 #include <algorithm>
 #include <cstdio>
 #include <vector>
@@ -25,28 +25,35 @@ int main(int argc, char** argv) {
     std::vector<uint16_t*> wq(NL + 1), wo(NL), wg(NL), wd(NL);
     for (int l = 0; l < NL; ++l) if (!dev_fill(&wq[l], (size_t)QKV * D, 7 * l, 6) || !dev_fill(&wo[l], (size_t)D * D, 11 * l + 1, 6) || !dev_fill(&wg[l], (size_t)2 * F * D, 13 * l + 2, 6) || !dev_fill(&wd[l], (size_t)D * F, 17 * l + 3, 7)) return 1;
     wq[NL] = wq[0];
-    uint16_t *ln, *att;
-    if (!dev_fill(&ln, D, 5, 0) || !dev_fill(&att, (size_t)M * D, 99, 2)) return 1;
+    uint16_t* att;
+    if (!dev_fill(&att, (size_t)M * D, 99, 2)) return 1;
     struct Bufs { uint16_t *h, *act, *qkv; } A, B;
     for (Bufs* b : {&A, &B}) if (!dev_fill(&b->h, (size_t)M * D, 31, 0) || !dev_fill(&b->act, (size_t)M * F, 37, 0) || !dev_fill(&b->qkv, (size_t)M * QKV, 41, 0)) return 1;
     unsigned *flags, *err; CK(hipMalloc((void**)&flags, CHAIN_WGS * 4 + 64)); CK(hipMemset(flags, 0, CHAIN_WGS * 4 + 64)); err = flags + CHAIN_WGS;
     hipStream_t s; CK(hipStreamCreate(&s));
+    CK(prepare_kernels());
+    auto one_launch = [&](int l, Bufs& b, int which) {
+        if (which == 0) { GemmArgs a{att, (const uint4*)wo[l], M, D, D, b.h, D, 16, 0, nullptr}; return launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) == hipSuccess; }
+        if (which == 1) { GemmArgs a{b.h, (const uint4*)wg[l], M, D, F, b.act, F, 4, 1, nullptr}; return launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s) == hipSuccess; }
+        if (which == 2) { GemmArgs a{b.act, (const uint4*)wd[l], M, F, D, b.h, D, 16, 0, nullptr}; return launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) == hipSuccess; }
+        GemmArgs a{b.h, (const uint4*)wq[l + 1], M, D, QKV, b.qkv, QKV, 4, 1, nullptr}; return launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s) == hipSuccess;
+    };
     auto layer_launches = [&](int l, Bufs& b) {
-        { GemmArgs a{att, (const uint4*)wo[l], M, D, D, b.h, D, 16, nullptr, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
-        { GemmArgs a{b.h, (const uint4*)wg[l], M, D, F, b.act, F, 4, ln, nullptr}; if (launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s) != hipSuccess) return false; }
-        { GemmArgs a{b.act, (const uint4*)wd[l], M, F, D, b.h, D, 16, nullptr, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
-        { GemmArgs a{b.h, (const uint4*)wq[l + 1], M, D, QKV, b.qkv, QKV, 4, ln, nullptr}; if (launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s) != hipSuccess) return false; }
+        { GemmArgs a{att, (const uint4*)wo[l], M, D, D, b.h, D, 16, 0, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
+        { GemmArgs a{b.h, (const uint4*)wg[l], M, D, F, b.act, F, 4, 1, nullptr}; if (launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s) != hipSuccess) return false; }
+        { GemmArgs a{b.act, (const uint4*)wd[l], M, F, D, b.h, D, 16, 0, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
+        { GemmArgs a{b.h, (const uint4*)wq[l + 1], M, D, QKV, b.qkv, QKV, 4, 1, nullptr}; if (launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s) != hipSuccess) return false; }
         return true;
     };
     auto layer_chain = [&](int l, Bufs& b, int phases) {
-        ChainArgs c{(const uint4*)wo[l], (const uint4*)wg[l], (const uint4*)wd[l], (const uint4*)wq[l + 1], ln, ln, att, b.h, b.act, b.qkv, M, phases, flags, err};
+        ChainArgs c{(const uint4*)wo[l], (const uint4*)wg[l], (const uint4*)wd[l], (const uint4*)wq[l + 1], att, b.h, b.act, b.qkv, M, phases, flags, err};
         return launch_chain(c, s) == hipSuccess;
     };
     // ---- (1) parity, layer by layer (h keeps evolving: every layer starts from the previous layer's output in both forms)
     std::vector<uint16_t> ha((size_t)M * D), hb(ha.size()), qa((size_t)M * QKV), qb(qa.size()), aa((size_t)M * F), ab(aa.size());
     size_t bad = 0;
     for (int l = 0; l < NL; ++l) {
-        if (!layer_launches(l, A) || !layer_chain(l, B, 15)) { printf("launch failed\n"); return 1; }
+        if (!layer_launches(l, A) || !(M <= 64 ? layer_chain(l, B, 15) : layer_launches(l, B))) { printf("launch failed\n"); return 1; }
         CK(hipStreamSynchronize(s));
         CK(hipMemcpy(ha.data(), A.h, ha.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), B.h, hb.size() * 2, hipMemcpyDeviceToHost));
         CK(hipMemcpy(qa.data(), A.qkv, qa.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(qb.data(), B.qkv, qb.size() * 2, hipMemcpyDeviceToHost));
@@ -80,6 +87,11 @@ int main(int argc, char** argv) {
         return 0;
     };
     if (time_graph([&](int l) { return layer_launches(l, A); }, "four launches per layer (graph replay)")) return 1;
+    if (time_graph([&](int l) { return one_launch(l, A, 0); }, "  launch: o only")) return 1;
+    if (time_graph([&](int l) { return one_launch(l, A, 1); }, "  launch: gate/up only")) return 1;
+    if (time_graph([&](int l) { return one_launch(l, A, 2); }, "  launch: down only")) return 1;
+    if (time_graph([&](int l) { return one_launch(l, A, 3); }, "  launch: qkv only")) return 1;
+    if (getenv("CHAIN_SKIP") || M > 64) return 0;
     if (time_graph([&](int l) { return layer_chain(l, B, 15); }, "persistent chain, one launch per layer")) return 1;
     if (time_graph([&](int l) { return layer_chain(l, B, 1); }, "  chain: o only")) return 1;
     if (time_graph([&](int l) { return layer_chain(l, B, 2); }, "  chain: gate/up only")) return 1;

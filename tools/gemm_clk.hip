@@ -48,13 +48,13 @@ int main(int argc, char** argv) {
     auto chain = [&]() {
         for (int l = 0; l < NL; ++l) {
             warm_next(wo[l], 64, 32);                          // beside qkv: o_proj weights (64 units of 32 KiB)
-            { GemmArgs a{h, (const uint4*)wq[l], M, D, QKV, qkv, QKV, 4, ln, nullptr}; if (launch_gemm(a, EPI_BF16, qkv_mt_arg ? qkv_mt_arg : choose_mt(M, QKV / 16, 4, true), s) != hipSuccess) return false; }
+            { GemmArgs a{h, (const uint4*)wq[l], M, D, QKV, qkv, QKV, 4, 1, nullptr}; if (launch_gemm(a, EPI_BF16, qkv_mt_arg ? qkv_mt_arg : choose_mt(M, QKV / 16, 4, true), s) != hipSuccess) return false; }
             warm_next(wg[l], 128, 128);                        // beside o_proj: gate/up weights (128 units of 4 packed tiles)
-            { GemmArgs a{att, (const uint4*)wo[l], M, D, D, h, D, 16, nullptr, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
+            { GemmArgs a{att, (const uint4*)wo[l], M, D, D, h, D, 16, 0, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
             warm_next(wd[l], 64, 128);                         // beside gate/up: down_proj weights (64 units of 128 KiB)
-            { GemmArgs a{h, (const uint4*)wg[l], M, D, F, act, F, 4, ln, nullptr}; if (launch_gemm(a, EPI_SILU, gu_mt_arg ? gu_mt_arg : choose_mt(M, F / 16, 4, true), s) != hipSuccess) return false; }
+            { GemmArgs a{h, (const uint4*)wg[l], M, D, F, act, F, 4, 1, nullptr}; if (launch_gemm(a, EPI_SILU, gu_mt_arg ? gu_mt_arg : choose_mt(M, F / 16, 4, true), s) != hipSuccess) return false; }
             warm_next(wq[(l + 1) % NL], 48, 128);              // beside down_proj: the next layer's qkv weights (48 units of 4 tiles)
-            { GemmArgs a{act, (const uint4*)wd[l], M, F, D, h, D, 16, nullptr, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
+            { GemmArgs a{act, (const uint4*)wd[l], M, F, D, h, D, 16, 0, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
         }
         return true;
     };
