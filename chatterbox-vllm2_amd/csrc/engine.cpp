@@ -54,6 +54,7 @@ struct Request {
     // request is still in flight (its slot is released when that step completes)
     int n_sched = 0, last_idx = -1;
     bool zombie = false;
+    int32_t* d_out = nullptr;         // finished: the utterance's speech-space ids on the device (f4 hand-off), from the engine's buffer pool
 };
 
 enum KClass { K_QKV, K_O, K_GU, K_DOWN, K_HEAD, K_ATTN, K_ROPE, K_EMBED, K_SAMPLE, K_COUNT };
@@ -124,6 +125,8 @@ struct T3Engine {
     uint16_t* d_counts = nullptr;
     T3Sampling* d_sp = nullptr;
     float* d_dbg = nullptr;
+    int32_t* d_hist = nullptr;         // [max_seqs][max_model_len]: the sampler appends every token it draws (slot-indexed)
+    std::vector<int32_t*> out_pool;    // free per-utterance device id buffers (max_model_len ints each)
 
     // scheduler
     std::unordered_map<int64_t, Request> reqs;
@@ -212,7 +215,9 @@ extern "C" int t3_destroy(T3Handle e) {
         }
         if (g.stream) (void)hipStreamDestroy(g.stream);
     }
-    free_dev(e->d_cond); free_dev(e->d_counts); free_dev(e->d_sp); free_dev(e->d_dbg);
+    free_dev(e->d_cond); free_dev(e->d_counts); free_dev(e->d_sp); free_dev(e->d_dbg); free_dev(e->d_hist);
+    for (auto* b : e->out_pool) free_dev(b);
+    for (auto& kv : e->reqs) free_dev(kv.second.d_out);
     if (e->ev_admit) (void)hipEventDestroy(e->ev_admit);
     for (int k = 0; k < K_COUNT; ++k) for (auto& p : e->pev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -391,6 +396,7 @@ extern "C" int t3_finalize_weights(T3Handle e) {
     if ((rc = dalloc(e, &e->d_counts, S * VPAD, true))) return rc;
     if ((rc = dalloc(e, &e->d_sp, S, true))) return rc;
     if (e->cfg.debug_logits && (rc = dalloc(e, &e->d_dbg, S * V, true))) return rc;
+    if ((rc = dalloc(e, &e->d_hist, S * (size_t)e->cfg.max_model_len, true))) return rc;
     e->h_block_table.assign(2 * S * e->max_blocks, 0);
     HIP_TRY(t3::prepare_kernels());
     // KV pool
@@ -532,7 +538,7 @@ static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec&
     if (n_sel > 0) {
         // final RMSNorm folded into the speech-head GEMM, which gathers the sampled rows itself
         { Prof p(e, K_HEAD, s); GemmArgs a{g.h, (const uint4*)e->head, 2 * n_sel, D, V, g.logits, VPAD, 4, 1, g.dm.sel_rows, HEAD_TILES}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16, 4, true), s)); }
-        { Prof p(e, K_SAMPLE, s); SampleArgs sa{g.logits, VPAD, g.dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, g.dm.out_tok, e->d_dbg, n_sel}; HIP_TRY(launch_sampler(sa, s)); }
+        { Prof p(e, K_SAMPLE, s); SampleArgs sa{g.logits, VPAD, g.dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, g.dm.out_tok, e->d_dbg, n_sel, e->d_hist, e->cfg.max_model_len}; HIP_TRY(launch_sampler(sa, s)); }
     }
     return T3_OK;
 }
@@ -679,6 +685,14 @@ static int complete_step(T3Engine* e, T3Engine::Step& st, T3StepResult* res) {
             else if ((int)r.out.size() >= r.limit) fin = 2;
             if (fin) {
                 r.state = FINISHED; r.finish_reason = fin;
+                {   // the ids stay on the device for the hand-off: out of the slot's history (the slot will be reused) into a buffer of the request's own.
+                    // Stream order does the rest: the copy runs behind the step that drew the last token and ahead of the slot's next occupant.
+                    if (e->out_pool.empty()) { int32_t* b = nullptr; if (hipMalloc((void**)&b, (size_t)e->cfg.max_model_len * 4) == hipSuccess) e->out_pool.push_back(b); }
+                    if (!e->out_pool.empty()) {
+                        r.d_out = e->out_pool.back(); e->out_pool.pop_back();
+                        (void)hipMemcpyAsync(r.d_out, e->d_hist + (size_t)r.slot * e->cfg.max_model_len, r.out.size() * 4, hipMemcpyDeviceToDevice, e->groups[gi].stream);
+                    }
+                }
                 if (res->n_finished < 64) res->finished_ids[res->n_finished] = r.id;
                 res->n_finished++;
                 if (r.n_sched > (int)r.out.size()) r.zombie = true;     // the step running ahead still uses its slot and KV blocks
@@ -763,7 +777,32 @@ extern "C" int t3_release_request(T3Handle e, int64_t req_id) {
     auto it = e->reqs.find(req_id);
     if (it == e->reqs.end()) return e->fail(T3_E_NOTFOUND, "unknown request id");
     if (it->second.state != FINISHED) return e->fail(T3_E_STATE, "request still running");
+    if (it->second.d_out) e->out_pool.push_back(it->second.d_out);
     e->reqs.erase(it);
+    return T3_OK;
+}
+
+// f4: batched hand-off of finished utterances to the vocoder (replaces the per-utterance loop of tts.py:483-514)
+extern "C" int t3_handoff_tokens(T3Handle e, const int64_t* req_ids, int32_t n, const int32_t* text_token_counts, int32_t flags,
+                                 int32_t* dev_tokens, int32_t ld, int32_t* dev_lens) {
+    if (!e || !req_ids || !text_token_counts || !dev_tokens || !dev_lens || n <= 0 || ld <= 0) return T3_E_INVALID;
+    (void)hipSetDevice(e->cfg.device_id);
+    std::vector<HandoffItem> items(n);
+    for (int i = 0; i < n; ++i) {
+        auto it = e->reqs.find(req_ids[i]);
+        if (it == e->reqs.end()) return e->fail(T3_E_NOTFOUND, "unknown request id");
+        const Request& r = it->second;
+        if (r.state != FINISHED || (!r.d_out && !r.out.empty())) return e->fail(T3_E_STATE, "request not finished (or its device ids were not kept)");
+        items[i] = HandoffItem{r.d_out, (int)r.out.size(), text_token_counts[i], 0};
+    }
+    for (auto& g : e->groups) HIP_TRY(hipStreamSynchronize(g.stream));        // the per-request copies were queued on the group streams
+    HandoffItem* d_items = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_items, items.size() * sizeof(HandoffItem)));
+    hipError_t err = hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(HandoffItem), hipMemcpyHostToDevice, e->stream);
+    if (err == hipSuccess) err = launch_handoff(d_items, n, flags, dev_tokens, ld, dev_lens, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_items);
+    HIP_TRY(err);
     return T3_OK;
 }
 
@@ -782,6 +821,7 @@ extern "C" int t3_abort_request(T3Handle e, int64_t req_id) {
         e->running.erase(std::remove(e->running.begin(), e->running.end(), req_id), e->running.end());
         release_slot(e, r);
     }
+    if (r.d_out) e->out_pool.push_back(r.d_out);
     e->reqs.erase(it);
     return T3_OK;
 }

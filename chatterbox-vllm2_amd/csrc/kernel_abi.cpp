@@ -161,6 +161,21 @@ extern "C" int t3k_sample(const void* logits2, int32_t ldl, uint16_t* counts, co
     return T3_OK;
 }
 
+/* the hand-off kernel on host buffers: ids [n] speech-space -> out [ld] (padded with 0), *len */
+extern "C" int t3k_handoff(const int32_t* ids, int32_t n, int32_t text_token_count, int32_t flags, int32_t* out, int32_t ld, int32_t* len) {
+    if ((!ids && n > 0) || !out || !len || n < 0 || ld <= 0) return T3_E_INVALID;
+    if (!have_device()) return T3_E_DEVICE;
+    DevBuf dids, ditem, dout, dlen;
+    K_TRY(dids.from(ids, (size_t)n * 4)); K_TRY(dout.alloc((size_t)ld * 4, true)); K_TRY(dlen.alloc(4, true));
+    const HandoffItem item{dids.as<int>(), n, text_token_count, 0};
+    K_TRY(ditem.from(&item, sizeof(item)));
+    K_TRY(launch_handoff(ditem.as<HandoffItem>(), 1, flags, dout.as<int>(), ld, dlen.as<int>(), nullptr));
+    K_TRY(hipDeviceSynchronize());
+    K_TRY(hipMemcpy(out, dout.p, (size_t)ld * 4, hipMemcpyDeviceToHost));
+    K_TRY(hipMemcpy(len, dlen.p, 4, hipMemcpyDeviceToHost));
+    return T3_OK;
+}
+
 extern "C" int t3k_expf(const float* x, float* y, int32_t n) {
     if (!x || !y || n <= 0) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;

@@ -101,10 +101,18 @@ struct SampleArgs {
     int* out_tok;              // [n]
     float* dbg;                // nullable: [max_seqs][V]
     int n;
+    int* hist = nullptr;       // nullable: [max_seqs][hist_cap] speech-space ids of every utterance, kept on the device (f4 hand-off)
+    int hist_cap = 0;
 };
 hipError_t launch_sampler(const SampleArgs& a, hipStream_t s);
 hipError_t prepare_kernels();   // one-time function attributes (must run before any stream capture)
 hipError_t launch_expf(const float* x, float* y, int n, hipStream_t s);
+
+// f4: batched token hand-off to the vocoder.  One workgroup per utterance applies the reference's post-filter (tts.py:300-365 +
+// alignment_stream_analyzer.py:111-201 + the range filter of tts.py:514 -- the same integer rules as t3_clean_tokens) to the
+// utterance's device-resident ids and writes one padded row + length.
+struct HandoffItem { const int* src; int n; int text_token_count; int _pad; };
+hipError_t launch_handoff(const HandoffItem* items /*device [n_utt]*/, int n_utt, int flags, int* out /*device [n_utt][ld]*/, int ld, int* lens /*device [n_utt]*/, hipStream_t s);
 
 void rope_tables(int max_pos, float* cos_t, float* sin_t);   // host, llama3 scaling, bf16-valued
 

@@ -831,6 +831,40 @@ hipError_t launch_rope_kv(const RopeArgs& a, hipStream_t s) {
 // (lane = token).  Per-chunk (m_c, l_c, o_c[64]) go to LDS; wave 0 folds them in ascending chunk order.
 // All orders are the contract's (DESIGN.md "Attention").
 // ------------------------------------------------------------------------------------------------
+// v[lane ^ off] for off = 32, 16, 8, 4, 2, 1 without the LDS crossbar (ds_bpermute costs a dependent ~100-cycle round trip per
+// level): gfx950's half / row swaps for 32 and 16, DPP row rotate / shifts / quad permutes below that.  Same pairing as __shfl_xor,
+// so the butterfly sums keep the contract's order.
+template <int OFF>
+__device__ __forceinline__ float lane_xor(float v, int lane) {
+    const int x = __float_as_int(v);
+    if constexpr (OFF == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);      // r[0] = {lo, lo}, r[1] = {hi, hi}
+        return __int_as_float((int)((lane & 32) ? r[0] : r[1]));
+    } else if constexpr (OFF == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);      // r[0] = even rows twice, r[1] = odd rows twice
+        return __int_as_float((int)((lane & 16) ? r[0] : r[1]));
+    } else if constexpr (OFF == 8) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, true));              // row_ror:8
+    } else if constexpr (OFF == 4) {
+        const int up = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0xf, true), dn = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shl:4 (from lane + 4), row_shr:4 (from lane - 4)
+        return __int_as_float((lane & 4) ? dn : up);
+    } else if constexpr (OFF == 2) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true));               // quad_perm [2,3,0,1]
+    } else {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true));               // quad_perm [1,0,3,2]
+    }
+}
+__device__ __forceinline__ float wave_max_f32(float m, int lane) {
+    m = fmaxf(m, lane_xor<32>(m, lane)); m = fmaxf(m, lane_xor<16>(m, lane)); m = fmaxf(m, lane_xor<8>(m, lane));
+    m = fmaxf(m, lane_xor<4>(m, lane)); m = fmaxf(m, lane_xor<2>(m, lane)); m = fmaxf(m, lane_xor<1>(m, lane));
+    return m;
+}
+__device__ __forceinline__ float wave_bfly_add_f32(float v, int lane) {      // contract order: xor 32, 16, 8, 4, 2, 1
+    v = v + lane_xor<32>(v, lane); v = v + lane_xor<16>(v, lane); v = v + lane_xor<8>(v, lane);
+    v = v + lane_xor<4>(v, lane); v = v + lane_xor<2>(v, lane); v = v + lane_xor<1>(v, lane);
+    return v;
+}
+
 __device__ __forceinline__ void patch16(uint4& v, int j, uint32_t val) {      // replace bf16 element j (0..7) of v
     const uint32_t sh = (j & 1) * 16, keep = ~(0xffffu << sh), ins = val << sh;
     const int w = j >> 1;
@@ -848,10 +882,11 @@ extern "C" int t3_debug_attn_clk(unsigned long long* out) { return (int)hipMemcp
 template <int NW, bool NT, bool FUSE>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(AttnArgs a) {
     T3_ASTAMP(0);
-    extern __shared__ __attribute__((aligned(16))) float part[];   // [max_chunks] m | [max_chunks] l | [max_chunks][64] o | per wave: 64 scores, 64 bf16 p
+    extern __shared__ __attribute__((aligned(16))) float part[];   // [max_chunks] m | [max_chunks] l | [max_chunks][64] o | per wave: 64 scores, 64 bf16 p | FUSE, per wave: [12][64] newest k / v
     float* pm = part; float* pl = part + a.max_chunks; float* po = part + 2 * a.max_chunks;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* sbuf = part + 66 * a.max_chunks + wave * 96;            // 64 floats of scores, then 64 bf16 (32 floats) of probabilities
+    uint32_t* stash = reinterpret_cast<uint32_t*>(part + 66 * a.max_chunks + NW * 96) + wave * (12 * 64) + (threadIdx.x & 63);   // FUSE: the newest key / value park here
     uint16_t* pbuf = reinterpret_cast<uint16_t*>(sbuf + 64);
     const int h = blockIdx.x, row = blockIdx.y;
     const int* rec = a.rowrec + (size_t)row * a.row_stride;
@@ -871,9 +906,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
 #pragma unroll
         for (int f = 0; f < 8; ++f) vf[f] = NT ? ld_nt(Vp + f * 64) : Vp[f * 64];
     };
+
     // the wave's first K/V tile is requested before anything else so that the q / RoPE prologue overlaps its flight
     if (wave < nc) load_tiles(wave);
-
     uint4 qfrag[2];                                 // B operand: q[32 ds + 8 kg .. +7], the same in all 16 columns
     uint4 knf[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};      // FUSE: the newest key in A-fragment form
     uint32_t vnew[4] = {0, 0, 0, 0};                // FUSE: the newest value, dims 16 dt + col
@@ -912,10 +947,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
         qfrag[0] = *reinterpret_cast<const uint4*>(qsrc); qfrag[1] = *reinterpret_cast<const uint4*>(qsrc + 32);
     }
 
+    if constexpr (FUSE) {
+        // the newest key / value wait in the wave's LDS corner until its last chunk: 12 registers less across the chunk loop,
+        // which sits at the 128-VGPR budget of four waves per SIMD (one more live value and hipcc spills a K/V tile register in
+        // the middle of the tile request, behind a full vmcnt(0))
+        stash[0 * 64] = knf[0].x; stash[1 * 64] = knf[0].y; stash[2 * 64] = knf[0].z; stash[3 * 64] = knf[0].w;
+        stash[4 * 64] = knf[1].x; stash[5 * 64] = knf[1].y; stash[6 * 64] = knf[1].z; stash[7 * 64] = knf[1].w;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) stash[(8 + dt) * 64] = vnew[dt];
+        asm volatile("" ::: "memory");
+    }
     T3_ASTAMP(1);                                   // prologue (q / RoPE / newest KV write) done
     for (int c = wave; c < nc; c += NW) {
         if (c != wave) load_tiles(c);
-        if (FUSE && c == nc - 1) {                  // the newest token is patched into the last tile from registers
+        if (FUSE && c == nc - 1) {                  // the newest token is patched into the last tile
+            knf[0] = make_uint4(stash[0 * 64], stash[1 * 64], stash[2 * 64], stash[3 * 64]);
+            knf[1] = make_uint4(stash[4 * 64], stash[5 * 64], stash[6 * 64], stash[7 * 64]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) vnew[dt] = stash[(8 + dt) * 64];
             const int tc = L - 1 - c * CHUNK;
             const int tts = tc >> 4, ts = tc & 15, tss = tc >> 5, kgs = (tc & 31) >> 3, js = tc & 7;
 #pragma unroll
@@ -960,6 +1009,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
         // ---- softmax statistics, lane = token
         const bool live = (c * CHUNK + lane) < L;
         const float sc = live ? sbuf[lane] * 0.125f : -INFINITY;
+#ifdef T3_ATTN_SHFL
         float m = sc;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -967,6 +1017,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
         float lsum = p;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) lsum = lsum + __shfl_xor(lsum, off);
+#else
+        const float m = wave_max_f32(sc, lane);
+        const float p = live ? t3_expf(sc - m) : 0.0f;
+        const float lsum = wave_bfly_add_f32(p, lane);
+#endif
         pbuf[lane] = (p < 0x1p-100f) ? (uint16_t)0 : (uint16_t)f2bf(p);
         asm volatile("" ::: "memory");
         uint4 pfrag[2];                             // B operand: p[32 ts + 8 kg .. +7] as bf16, the same in all 16 columns
@@ -993,25 +1048,27 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
     __syncthreads();
     T3_ASTAMP(4);
     if (wave == 0) {
-        // fold in ascending chunk order (contract); four chunks' LDS reads are issued together, the fma chain stays sequential
+        // fold in ascending chunk order (contract).  M and the weights w_c = exp(m_c - M) do not depend on the order: lanes compute
+        // them side by side (into the m slots); the sequential part is two fmas per chunk on LDS operands.
         float M = -INFINITY;
-#pragma unroll 4
-        for (int c = 0; c < nc; ++c) M = fmaxf(M, pm[c]);
+        for (int c0 = 0; c0 < nc; c0 += 64) M = fmaxf(M, (c0 + lane < nc) ? pm[c0 + lane] : -INFINITY);
+        M = wave_max_f32(M, lane);
+        for (int c0 = 0; c0 < nc; c0 += 64) if (c0 + lane < nc) pm[c0 + lane] = t3_expf(pm[c0 + lane] - M);
+        asm volatile("" ::: "memory");
         float l = 0.0f, o = 0.0f;
         int c = 0;
         for (; c + 4 <= nc; c += 4) {
-            float mc[4], lc[4], oc[4];
+            float wc[4], lc[4], oc[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { mc[u] = pm[c + u]; lc[u] = pl[c + u]; oc[u] = po[(c + u) * 64 + lane]; }
+            for (int u = 0; u < 4; ++u) { wc[u] = pm[c + u]; lc[u] = pl[c + u]; oc[u] = po[(c + u) * 64 + lane]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float w = t3_expf(mc[u] - M);
-                l = __builtin_fmaf(w, lc[u], l);
-                o = __builtin_fmaf(w, oc[u], o);
+                l = __builtin_fmaf(wc[u], lc[u], l);
+                o = __builtin_fmaf(wc[u], oc[u], o);
             }
         }
         for (; c < nc; ++c) {
-            const float w = t3_expf(pm[c] - M);
+            const float w = pm[c];
             l = __builtin_fmaf(w, pl[c], l);
             o = __builtin_fmaf(w, po[c * 64 + lane], o);
         }
@@ -1028,7 +1085,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     const int nw = nw_env == 4 || nw_env == 8 ? nw_env : (a.rows <= 8 ? 8 : 4);
     const dim3 grid(H, a.rows);
     const bool fuse = a.qkv != nullptr;
-    const size_t lds = ((size_t)a.max_chunks * 66 + (size_t)(nw == 8 ? 8 : 4) * 96) * sizeof(float);
+    const size_t lds = ((size_t)a.max_chunks * 66 + (size_t)(nw == 8 ? 8 : 4) * (96 + (fuse ? 12 * 64 : 0))) * sizeof(float);
 #define T3_ATTN(NW, NTF, FU) hipLaunchKernelGGL((attention_kernel<NW, NTF, FU>), grid, dim3(NW * 64), lds, s, a)
     if (nw == 8) { if (fuse) { if (nt) T3_ATTN(8, true, true); else T3_ATTN(8, false, true); } else { if (nt) T3_ATTN(8, true, false); else T3_ATTN(8, false, false); } }
     else { if (fuse) { if (nt) T3_ATTN(4, true, true); else T3_ATTN(4, false, true); } else { if (nt) T3_ATTN(4, true, false); else T3_ATTN(4, false, false); } }
@@ -1332,6 +1389,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
     if (tid == 0) {
         token = token < 0 ? 0 : (token >= V ? V - 1 : token);       // counts[] / speech_emb[] are indexed with it
         a.out_tok[u] = token;
+        if (a.hist && (int)step < a.hist_cap) a.hist[(size_t)slot * a.hist_cap + step] = token;      // the utterance's ids stay on the device
         const uint16_t cnt = counts[token];
         if (cnt < 65535) counts[token] = cnt + 1;
 #ifdef T3_SAMPLER_CLK
@@ -1354,6 +1412,53 @@ hipError_t launch_sampler(const SampleArgs& a, hipStream_t s) {
     hipError_t e = prepare_kernels();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sampler_kernel, dim3(a.n), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// f4 hand-off: post-filter + range filter + padding of one utterance per workgroup (see t3_kernels.h).  The analyzer's rules in
+// closed form: it forces EOS at the first index i >= 2 with ids[i] == ids[i-1] == ids[i-2], or at index completed_at + 9 where
+// completed_at = max(1, 2 (text_token_count - 3)) is the first frame whose estimated text position (frame / 2, capped at
+// text_token_count - 1) reaches text_token_count - 3; the kept tokens are the prefix before that index (t3_clean_tokens).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void handoff_kernel(const HandoffItem* items, int flags, int* out, int ld, int* lens) {
+    __shared__ int s_min[4], s_cnt[4], s_base;
+    const HandoffItem it = items[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int first_rep = 0x7fffffff;
+    for (int i = 2 + tid; i < it.n; i += 256)
+        if (it.src[i] == it.src[i - 1] && it.src[i] == it.src[i - 2]) { first_rep = i; break; }       // ascending per thread: its first hit is its minimum
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) first_rep = min(first_rep, __shfl_xor(first_rep, off));
+    if (lane == 0) s_min[wave] = first_rep;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    first_rep = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+    const int completed_at = max(1, 2 * (it.text_token_count - 3));
+    const int cut = min(min(first_rep, completed_at + 9), it.n);
+    int* row = out + (size_t)blockIdx.x * ld;
+    for (int base = 0; base < cut; base += 256) {
+        const int i = base + tid;
+        const int v = i < cut ? it.src[i] : -1;
+        const bool keep = i < cut && (!(flags & 1) || (v >= 0 && v < 6561));
+        const unsigned long long m = __ballot(keep);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int pre = s_base;
+        for (int w = 0; w < wave; ++w) pre += s_cnt[w];
+        if (keep && pre + before < ld) row[pre + before] = v;
+        __syncthreads();
+        if (tid == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+    const int kept = min(s_base, ld);
+    for (int i = kept + tid; i < ld; i += 256) row[i] = 0;
+    if (tid == 0) lens[blockIdx.x] = kept;
+}
+hipError_t launch_handoff(const HandoffItem* items, int n_utt, int flags, int* out, int ld, int* lens, hipStream_t s) {
+    if (n_utt <= 0) return hipSuccess;
+    hipLaunchKernelGGL(handoff_kernel, dim3(n_utt), dim3(256), 0, s, items, flags, out, ld, lens);
     return hipGetLastError();
 }
 

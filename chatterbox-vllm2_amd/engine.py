@@ -60,7 +60,7 @@ class T3Stats(ct.Structure):
 # every symbol include/t3_engine.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
     "t3_create", "t3_destroy", "t3_last_error", "t3_load_tensor", "t3_finalize_weights", "t3_add_request",
-    "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_release_request", "t3_abort_request",
+    "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_release_request", "t3_abort_request", "t3_handoff_tokens", "t3k_handoff",
     "t3_clean_tokens", "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_set_profile_kernel", "t3_kernel_ms",
     "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_sample", "t3k_expf",
     "t3_cond_create", "t3_cond_destroy", "t3_cond_last_error", "t3_cond_load_tensor", "t3_cond_encode", "t3_cond_emotion_row",
@@ -104,6 +104,8 @@ def load_library():
     L.t3_get_output.argtypes = [vp, i64, vp, ct.POINTER(i32), ct.POINTER(i32)]
     L.t3_release_request.argtypes = [vp, i64]
     L.t3_abort_request.argtypes = [vp, i64]
+    L.t3_handoff_tokens.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]
+    L.t3k_handoff.argtypes = [vp, i32, i32, i32, vp, i32, ct.POINTER(i32)]
     L.t3_clean_tokens.argtypes = [vp, i32, i32, i32, vp, ct.POINTER(i32)]
     L.t3_debug_logits.argtypes = [vp, i64, vp]
     L.t3_stats.argtypes = [vp, ct.POINTER(T3Stats)]
@@ -242,6 +244,25 @@ class T3Engine:
     def release(self, req_id: int):
         self._chk(self.lib.t3_release_request(self.h, int(req_id)))
 
+    def handoff_tokens(self, req_ids: Sequence[int], text_token_counts: Sequence[int], range_filter: bool = True):
+        """f4: the finished utterances' ids, post-filtered (tts.py:300-365) and range-filtered (tts.py:514) ON THE DEVICE, as one padded
+        batch: (speech_tokens int32 [n, L] cuda tensor, speech_token_lens int32 [n] cuda tensor).  The ids never visit the host."""
+        n = len(req_ids)
+        rid = np.ascontiguousarray(np.asarray(req_ids, dtype=np.int64)); tc = np.ascontiguousarray(np.asarray(text_token_counts, dtype=np.int32))
+        if n == 0 or len(tc) != n:
+            raise ValueError("handoff_tokens needs one text_token_count per request id")
+        ld = 1
+        for r in req_ids:
+            cnt = ct.c_int32(0); fr = ct.c_int32(0)
+            self._chk(self.lib.t3_get_output(self.h, int(r), None, ct.byref(cnt), ct.byref(fr)))
+            ld = max(ld, int(cnt.value))
+        dev = torch.device("cuda", int(self.cfg.device_id))
+        toks = torch.empty(n, ld, dtype=torch.int32, device=dev); lens = torch.empty(n, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        self._chk(self.lib.t3_handoff_tokens(self.h, ct.c_void_p(rid.ctypes.data), n, ct.c_void_p(tc.ctypes.data), int(bool(range_filter)),
+                                             ct.c_void_p(toks.data_ptr()), ld, ct.c_void_p(lens.data_ptr())))
+        return toks, lens
+
     def abort(self, req_id: int):
         """Drop a request in any state (a waiting one leaves the queue, a running one frees its slot and KV blocks)."""
         self._chk(self.lib.t3_abort_request(self.h, int(req_id)))
@@ -337,6 +358,14 @@ def k_sample(logits2: torch.Tensor, counts: torch.Tensor, sp: T3Sampling, cfg: f
     _chk_k(load_library().t3k_sample(logits2.data_ptr(), logits2.shape[1], counts.data_ptr(), ct.byref(sp), ct.c_float(cfg),
                                      ct.c_uint32(step), ct.byref(tok), lg.data_ptr()), "t3k_sample")
     return int(tok.value), lg
+
+
+def k_handoff(ids, text_token_count: int, flags: int = 1, ld: int = 0):
+    """the hand-off kernel on one utterance's speech-space ids -> (kept ids list, padded row as list)"""
+    a = np.ascontiguousarray(np.asarray(ids, dtype=np.int32)); ld = ld or max(1, len(a))
+    out = np.zeros(ld, dtype=np.int32); n = ct.c_int32(0)
+    _chk_k(load_library().t3k_handoff(a.ctypes.data if len(a) else None, len(a), int(text_token_count), int(flags), out.ctypes.data, ld, ct.byref(n)), "t3k_handoff")
+    return out[: n.value].tolist(), out.tolist()
 
 
 def k_expf(x: torch.Tensor) -> torch.Tensor:

@@ -151,14 +151,17 @@ class LLM:
         return p["prompt"], self.tokenizer.encode(p["prompt"]), cond
 
     def generate(self, prompts: Union[PromptType, Sequence[PromptType]], sampling_params: Optional[Union[SamplingParams, Sequence[SamplingParams]]] = None,
-                 use_tqdm: bool = False, uid_base: Optional[int] = None, uids: Optional[Sequence[int]] = None) -> List[RequestOutput]:
+                 use_tqdm: bool = False, uid_base: Optional[int] = None, uids: Optional[Sequence[int]] = None,
+                 keep_for_handoff: bool = False) -> List[RequestOutput]:
         """Randomness (the sampler draws from Philox keyed by (seed, uid, step), include/t3_engine.h):
           * no SamplingParams.seed (what tts.py:455-464 does): every request takes the next RNG stream of this LLM object, so the
             same text submitted twice gives two different utterances, while a fresh process replays the same sequence -- vLLM's
             behaviour with its global `seed=0` default;
           * SamplingParams.seed given: that request is reproducible wherever it sits (vLLM's per-request generator);
           * uids (one per prompt) or uid_base (request i uses uid_base + i) given -- the data-parallel launcher, dp.py: the stream
-            is the utterance's GLOBAL index, so a sharded run emits the ids of the one-GPU run."""
+            is the utterance's GLOBAL index, so a sharded run emits the ids of the one-GPU run.
+        keep_for_handoff: the requests stay in the engine (finished) until `handoff_tokens(outputs, ...)` hands their ids to the
+        vocoder from device memory; without it they are released here, as the reference's flow expects."""
         if isinstance(prompts, (str, dict)):
             prompts = [prompts]
         if sampling_params is None:
@@ -192,12 +195,28 @@ class LLM:
         outs = []
         for rid, text, final in metas:
             toks, fr = self.engine.get_output(rid)
-            self.engine.release(rid)
+            if not keep_for_handoff:
+                self.engine.release(rid)
             reason = {1: "stop", 2: "length"}.get(fr)
             outs.append(RequestOutput(request_id=str(rid), prompt=text, prompt_token_ids=final,
                                       outputs=[CompletionOutput(index=0, text="", token_ids=toks, finish_reason=reason,
                                                                 stop_reason=(toks[-1] if fr == 1 else None))]))
         return outs
+
+    def handoff_tokens(self, outputs: Sequence[RequestOutput], text_token_counts: Sequence[int], range_filter: bool = True):
+        """The T3 -> S3Gen hand-off for a whole batch (replaces the loop of tts.py:483-514): for outputs of
+        `generate(..., keep_for_handoff=True)` returns (speech_tokens int32 [n, L], speech_token_lens int32 [n]) CUDA tensors --
+        ids already un-offset, cut where the reference's AlignmentStreamAnalyzer would force EOS (text_token_counts as tts.py:496:
+        `len(prompt.split()) * 2`), filtered to [0, 6561) -- and releases the requests."""
+        rids = [int(o.request_id) for o in outputs]
+        try:
+            return self.engine.handoff_tokens(rids, text_token_counts, range_filter)
+        finally:
+            for r in rids:
+                try:
+                    self.engine.release(r)
+                except Exception:
+                    pass
 
     def _queue(self, prompts, sps, uids, metas, queued):
         for i, (p, sp) in enumerate(zip(prompts, sps)):

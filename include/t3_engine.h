@@ -143,6 +143,19 @@ int t3_abort_request(T3Handle h, int64_t req_id);
 int t3_clean_tokens(const int32_t* speech_ids, int32_t n, int32_t text_token_count, int32_t flags,
                     int32_t* out, int32_t* reason);
 
+/* ---- T3 -> S3Gen hand-off --------------------------------------------------------------------------
+ * Replaces the per-utterance loop of ChatterboxTTS.generate_with_conds after the engine call (tts.py:483-514): `token - 2500`,
+ * analyze_and_clean_tokens (one CUDA tensor + .item() sync per token, tts.py:335-344), torch.tensor(ids, device="cuda")
+ * (tts.py:365) and the [0, 6561) mask (tts.py:514), once per utterance.  Here the ids never leave the device: the sampler keeps
+ * every utterance's ids in HBM, and this call filters, compacts and pads a whole batch in one launch, straight into the caller's
+ * DEVICE buffers in the layout a batched vocoder front-end takes (speech_tokens [n][ld] int32, speech_token_lens [n]; the
+ * reference's flow.inference asserts batch 1, flow.py:256, so today's caller slices row i to lens[i]).
+ * req_ids: n FINISHED, not yet released requests; text_token_counts as tts.py:496; flags bit 0: range filter of tts.py:514.
+ * dev_tokens: device int32 [n][ld], rows padded with 0 beyond lens; dev_lens: device int32 [n].  Returns when the buffers are
+ * ready (the call synchronises its own stream).                                                                        */
+int t3_handoff_tokens(T3Handle h, const int64_t* req_ids, int32_t n, const int32_t* text_token_counts, int32_t flags,
+                      int32_t* dev_tokens, int32_t ld, int32_t* dev_lens);
+
 /* ---- parity / measurement hooks --------------------------------------------------------- */
 /* post-CFG logits [8194] (speech-space, before the 2500-wide -inf pad of t3.py:669-672) of the
  * most recent sampled step of req_id; needs cfg.debug_logits = 1. */
@@ -206,6 +219,8 @@ int t3k_rope_attention(const void* qkv_bf16, const int32_t* row_stream, const in
 int t3k_sample(const void* logits2_bf16, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg,
                uint32_t step, int32_t* token_out, float* logits_out_8194 /*nullable*/);
 int t3k_expf(const float* x, float* y, int32_t n);
+/* the hand-off kernel on host buffers (one utterance): out [ld] padded with 0, *len = kept tokens */
+int t3k_handoff(const int32_t* speech_ids, int32_t n, int32_t text_token_count, int32_t flags, int32_t* out, int32_t ld, int32_t* len);
 /* Row count from which the GEMM launcher switches to its prefill schedule (same numbers, LDS-tiled); process-wide.
  * < 0 restores the default (1024).  For the parity tests, which check the prefill schedule at small row counts. */
 int t3k_set_prefill_rows(int32_t rows);

@@ -394,3 +394,26 @@ def test_data_parallel_llm_world2_equals_world1(tmp_path):
     two = run(2, 29572)
     assert two[0] == one and two[1] == one
     assert len(one) == 7 and all(len(t) == 12 + 5 * (i % 3) for i, t in enumerate(one))
+
+
+def test_handoff_keeps_ids_on_the_device(E, cond):
+    """f4 (tts.py:483-514 as one call): 9 utterances through 3 slots (slots are reused while earlier utterances wait for the hand-off);
+    the padded device batch equals the host post-filter (pinned to the reference's analyzer) applied to the ids `LLM.generate` returned."""
+    from chatterbox_vllm2_amd import LLM, SamplingParams
+    from chatterbox_vllm2_amd.postfilter import analyze_and_clean_tokens
+    llm = LLM(model="", tokenizer="EnTokenizer", load_format="dummy", num_hidden_layers=2, max_model_len=300, max_num_seqs=3, kv_cache_bytes=1 << 28)
+    prompts = [{"prompt_token_ids": make_prompt(6 + 2 * i, seed=70 + i)[34:-1], "multi_modal_data": {"conditionals": [cond]}} for i in range(9)]
+    sps = [SamplingParams(temperature=0.8 if i % 3 else 0.0, top_p=0.8, repetition_penalty=2.0 if i % 2 else 1.0, max_tokens=40 + 23 * i, stop_token_ids=[9062]) for i in range(9)]
+    outs = llm.generate(prompts, sps, keep_for_handoff=True)
+    counts = [2 * (3 + i) for i in range(9)]                      # tts.py:496: len(prompt.split()) * 2
+    toks, lens = llm.handoff_tokens(outs, counts)
+    assert toks.is_cuda and toks.dtype == torch.int32 and tuple(toks.shape) == (9, max(len(o.outputs[0].token_ids) for o in outs))
+    toks, lens = toks.cpu(), lens.cpu()
+    for i, o in enumerate(outs):
+        want, _ = analyze_and_clean_tokens([t - 2500 for t in o.outputs[0].token_ids], counts[i], range_filter=True)
+        assert toks[i, : int(lens[i])].tolist() == want and not toks[i, int(lens[i]):].any()
+    assert any(int(lens[i]) < len(o.outputs[0].token_ids) for i, o in enumerate(outs))        # greedy streams repeat: the filter did cut something
+    assert llm.engine.num_unfinished() == 0
+    with pytest.raises(E.T3Error):
+        llm.engine.handoff_tokens([int(outs[0].request_id)], [4])                              # released by the hand-off
+    llm.shutdown()

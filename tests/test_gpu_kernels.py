@@ -204,3 +204,23 @@ def test_sampler_counts_update(E):
     counts = torch.zeros(8194, dtype=torch.uint16)
     tok, _ = E.k_sample(l, counts, E.make_sampling(temperature=0.0), 0.5, 0)
     assert tok == 100 and int(counts[100]) == 1 and int(counts.to(torch.int32).sum()) == 1
+
+
+def test_handoff_kernel_matches_reference_analyzer_decisions(E):
+    """f4: the device hand-off kernel against the 128 cases recorded from the reference's own AlignmentStreamAnalyzer
+    (tests/golden/postfilter.json, make_golden.py g8) and against the host restatement t3_clean_tokens on the same inputs."""
+    import json, os
+    from chatterbox_vllm2_amd.postfilter import analyze_and_clean_tokens
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "postfilter.json")))
+    assert len(cases) >= 100
+    for c in cases:
+        kept, row = E.k_handoff(c["tokens"], c["text_token_count"], flags=0, ld=max(1, len(c["tokens"])) + 3)
+        assert kept == c["cleaned"], (c["text_token_count"], len(c["tokens"]))
+        assert all(v == 0 for v in row[len(kept):])                                     # padding
+        want = [t for t in c["cleaned"] if 0 <= t < 6561]                               # tts.py:514
+        assert E.k_handoff(c["tokens"], c["text_token_count"], flags=1)[0] == want
+        assert want == analyze_and_clean_tokens(c["tokens"], c["text_token_count"], range_filter=True)[0]
+    rs = np.random.RandomState(5)                                                       # long utterances: several 256-token sweeps
+    for n, tc in ((1000, 400), (777, 600), (300, 2), (0, 5)):
+        ids = rs.randint(0, 8194, size=n).tolist()
+        assert E.k_handoff(ids, tc, flags=1)[0] == analyze_and_clean_tokens(ids, tc, range_filter=True)[0]
