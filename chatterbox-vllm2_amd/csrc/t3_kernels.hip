@@ -411,35 +411,48 @@ __global__ __launch_bounds__(256) void row_rstd_kernel(const uint16_t* h, float*
     if ((c >> 2) == q && mt * 16 + c < rows) rstd[mt * 16 + c] = 1.0f / sqrtf(tot * (1.0f / 1024.0f) + 1e-5f);
 }
 
+__device__ __forceinline__ int pgemm_a_pos(int row, int q) { return (row << 2) + (((row >> 2) & 3) ^ ((4 - q) & 3)); }     // uint4 index in a stage's A image
+// one 1 KiB LDS-DMA piece: every lane's 16 bytes at gsrc land at lds_byte_addr (wave-uniform) + 16 * lane.  M0 carries the LDS
+// address and is written in the statement that uses it (cdna_hip_programming.md 5.7); hipcc does not count this load: every wait
+// for it below is hand-counted.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
 template <int EPI, int NSEG, bool NORM>
-__global__ __launch_bounds__(256, NSEG == 4 ? 4 : 2) void pgemm_kernel(GemmArgs a, const float* rstd) {
-    __shared__ __attribute__((aligned(16))) uint4 As[2][512], Bs[2][256];     // per stage: 128 rows x 64 B; 4 fragments x 1 KiB
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+__global__ __launch_bounds__(256, NSEG == 4 ? 4 : 3) void pgemm_kernel(GemmArgs a, const float* rstd) {
+    // Operand ring in LDS, filled by LDS-DMA three K steps ahead of the MFMAs (no staging registers: the global-load latency of
+    // a step is covered by three steps of arithmetic instead of one).  Per stage: A image 128 rows x 64 B (swizzled, below) | 4
+    // weight fragments x 1 KiB.  The NORM forms' activations go in untouched (the norm weight lives in the packed matrix).
+#ifndef T3_PGEMM_NS
+#define T3_PGEMM_NS 3      // measured at 8192 rows: 3 stages (36 KiB, 4 workgroups per CU) 214 / 92 / 91 us (gate-up / o+down / qkv), 4 stages 235 / 91 / 99, 6 stages 296 / 96 / 121
+#endif
+    constexpr int NS = T3_PGEMM_NS, AHEAD = NS - 1, STAGE = 768;               // stages in the ring; uint4 per stage
+    __shared__ __attribute__((aligned(16))) uint4 ring[NS * STAGE];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 1, wc = wave & 1;                                   // wave tile: rows 64 wr .., packed n-tiles 2 wc, 2 wc + 1
     const int KB = a.K >> 5, kbs = KB / NSEG;
     const int m0 = blockIdx.y * 128, nt0 = blockIdx.x * 4;
-    // staging assignment: two activation pieces (row, q) and one weight piece per thread
-    const uint4* xsrc[2];
+    // A image: 64-byte rows, so four rows share a 256-byte bank row and the 16 rows of a fragment read would hit 4 bank slots.
+    // Chunk q of row r sits at position ((r >> 2) & 3) ^ T[q], T = {0, 3, 2, 1} (an involution): the 16 lanes of each hardware
+    // lane group of ds_read_b128 then land on 16 different slots.  A DMA piece writes LDS linearly, so the permutation is applied
+    // to the SOURCE: the lane that fills position P = 4 row + p fetches chunk q = T[p ^ ((row >> 2) & 3)] of that row.
+    const uint16_t* xsrc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int pce = t + 256 * j, row = pce >> 2, q = pce & 3;
+        const int P = t + 256 * j, row = P >> 2, q = (4 - ((P & 3) ^ ((row >> 2) & 3))) & 3;
         int m = m0 + row; m = m < a.M ? m : a.M - 1;
-        xsrc[j] = reinterpret_cast<const uint4*>(a.X + (size_t)m * a.K + q * 8);
+        xsrc[j] = a.X + (size_t)m * a.K + q * 8;
     }
-    const uint4* wsrc = a.Wp + ((size_t)(nt0 + (t >> 6)) * KB) * 64 + lane;
-    uint4 xa[2], wb;
-    auto fetch = [&](int kb) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) xa[j] = xsrc[j][kb * 4];
-        wb = ld_nt(wsrc + (size_t)kb * 64);
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint4 v = xa[j];
-            As[buf][t + 256 * j] = v;
-        }
-        Bs[buf][t] = wb;
+    const uint4* wsrc = a.Wp + ((size_t)(nt0 + wave) * KB) * 64 + lane;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
+    auto issue = [&](int kb) {                                                 // three 1 KiB pieces per wave and stage
+        const unsigned base = lds0 + (unsigned)(((kb % NS) * STAGE + wave * 64) * 16);
+        glds16(xsrc[0] + kb * 32, base);
+        glds16(xsrc[1] + kb * 32, base + 256 * 16);
+        glds16(wsrc + (size_t)kb * 64, base + 512 * 16);
     };
     f32x4 sg[4][2], gr[4][2], tot[4][2];
 #pragma unroll
@@ -447,18 +460,31 @@ __global__ __launch_bounds__(256, NSEG == 4 ? 4 : 2) void pgemm_kernel(GemmArgs 
 #pragma unroll
         for (int u = 0; u < 2; ++u) { sg[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f}; gr[i][u] = sg[i][u]; tot[i][u] = sg[i][u]; }
 
-    fetch(0);
-    stage(0);
-    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < AHEAD; ++k0) if (k0 < KB) issue(k0);
     int kin = 0, seg = 0;
     for (int kb = 0; kb < KB; ++kb) {
-        const int buf = kb & 1;
-        if (kb + 1 < KB) fetch(kb + 1);
+        // stage kb has landed once every wave has seen its own three pieces of it: vmcnt retires in issue order, the pieces of the
+        // (up to two) younger stages may still fly.  lgkmcnt(0): this wave's fragment reads of the previous step are back, so the
+        // buffer that is refilled below is free.  A raw barrier: __syncthreads() would drain the DMA queue.
+        const int younger = KB - 1 - kb < AHEAD - 1 ? KB - 1 - kb : AHEAD - 1;      // stages behind this one that may still be in flight
+        switch (younger) {
+            case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(15) lgkmcnt(0)" ::: "memory"); break;
+        }
+        __builtin_amdgcn_s_barrier();
+        const uint4* As = ring + (kb % NS) * STAGE;
+        const uint4* Bs = As + 512;
         uint4 af[4], bf[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = As[buf][(wr * 64 + i * 16 + (lane & 15)) * 4 + (lane >> 4)];
+        for (int i = 0; i < 4; ++i) af[i] = As[pgemm_a_pos(wr * 64 + i * 16 + (lane & 15), lane >> 4)];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) bf[u] = Bs[buf][(wc * 2 + u) * 64 + lane];
+        for (int u = 0; u < 2; ++u) bf[u] = Bs[(wc * 2 + u) * 64 + lane];
+        if (kb + AHEAD < KB) issue(kb + AHEAD);          // into the buffer of step kb - 1: every wave is past its reads (barrier above)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -479,8 +505,6 @@ __global__ __launch_bounds__(256, NSEG == 4 ? 4 : 2) void pgemm_kernel(GemmArgs 
                 }
             kin = 0; ++seg;
         }
-        if (kb + 1 < KB) stage(buf ^ 1);
-        __syncthreads();
     }
     // epilogue: D[row = 4 (lane >> 4) + r][col = lane & 15] of every 16 x 16 tile
 #pragma unroll
@@ -653,8 +677,11 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             const int groups = ((a.M + 15) / 16 + mt - 1) / mt;
             const int want = epi == EPI_SILU ? 256 : 192;
             int pick = 0;
+            // a 2 x 4 workgroup holds 32 weight tiles + 16 activation pieces in registers: one workgroup per CU.  A grid a little over
+            // 256 of those (the speech head at 64 rows: 129 x 2 = 258) would run a second, almost empty round: take the next group size
+            auto partial_round = [&](int c) { const long w = (long)(ntiles / c) * groups; return mt * c >= 8 && w > 256 && w < 512; };
             for (int c = 4; c > nt && !pick; --c)
-                if ((epi != EPI_SILU || c % 2 == 0) && ntiles % c == 0 && (long)(ntiles / c) * groups >= 256) pick = c;
+                if ((epi != EPI_SILU || c % 2 == 0) && ntiles % c == 0 && (long)(ntiles / c) * groups >= 256 && !partial_round(c)) pick = c;
             for (int c = 4; c > nt && !pick; --c)
                 if ((epi != EPI_SILU || c % 2 == 0) && ntiles % c == 0 && (long)(ntiles / c) * groups >= want) pick = c;
             if (pick) nt = pick;

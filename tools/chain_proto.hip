@@ -29,20 +29,21 @@ int main(int argc, char** argv) {
     if (!dev_fill(&att, (size_t)M * D, 99, 2)) return 1;
     struct Bufs { uint16_t *h, *act, *qkv; } A, B;
     for (Bufs* b : {&A, &B}) if (!dev_fill(&b->h, (size_t)M * D, 31, 0) || !dev_fill(&b->act, (size_t)M * F, 37, 0) || !dev_fill(&b->qkv, (size_t)M * QKV, 41, 0)) return 1;
+    float* rstd; CK(hipMalloc((void**)&rstd, (size_t)M * 4));
     unsigned *flags, *err; CK(hipMalloc((void**)&flags, CHAIN_WGS * 4 + 64)); CK(hipMemset(flags, 0, CHAIN_WGS * 4 + 64)); err = flags + CHAIN_WGS;
     hipStream_t s; CK(hipStreamCreate(&s));
     CK(prepare_kernels());
     auto one_launch = [&](int l, Bufs& b, int which) {
         if (which == 0) { GemmArgs a{att, (const uint4*)wo[l], M, D, D, b.h, D, 16, 0, nullptr}; return launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) == hipSuccess; }
-        if (which == 1) { GemmArgs a{b.h, (const uint4*)wg[l], M, D, F, b.act, F, 4, 1, nullptr}; return launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s) == hipSuccess; }
+        if (which == 1) { GemmArgs a{b.h, (const uint4*)wg[l], M, D, F, b.act, F, 4, 1, nullptr, 0, rstd}; return launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s) == hipSuccess; }
         if (which == 2) { GemmArgs a{b.act, (const uint4*)wd[l], M, F, D, b.h, D, 16, 0, nullptr}; return launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) == hipSuccess; }
-        GemmArgs a{b.h, (const uint4*)wq[l + 1], M, D, QKV, b.qkv, QKV, 4, 1, nullptr}; return launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s) == hipSuccess;
+        GemmArgs a{b.h, (const uint4*)wq[l + 1], M, D, QKV, b.qkv, QKV, 4, 1, nullptr, 0, rstd}; return launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s) == hipSuccess;
     };
     auto layer_launches = [&](int l, Bufs& b) {
         { GemmArgs a{att, (const uint4*)wo[l], M, D, D, b.h, D, 16, 0, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
-        { GemmArgs a{b.h, (const uint4*)wg[l], M, D, F, b.act, F, 4, 1, nullptr}; if (launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s) != hipSuccess) return false; }
+        { GemmArgs a{b.h, (const uint4*)wg[l], M, D, F, b.act, F, 4, 1, nullptr, 0, rstd}; if (launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s) != hipSuccess) return false; }
         { GemmArgs a{b.act, (const uint4*)wd[l], M, F, D, b.h, D, 16, 0, nullptr}; if (launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s) != hipSuccess) return false; }
-        { GemmArgs a{b.h, (const uint4*)wq[l + 1], M, D, QKV, b.qkv, QKV, 4, 1, nullptr}; if (launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s) != hipSuccess) return false; }
+        { GemmArgs a{b.h, (const uint4*)wq[l + 1], M, D, QKV, b.qkv, QKV, 4, 1, nullptr, 0, rstd}; if (launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s) != hipSuccess) return false; }
         return true;
     };
     auto layer_chain = [&](int l, Bufs& b, int phases) {
