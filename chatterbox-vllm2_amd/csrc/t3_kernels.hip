@@ -379,6 +379,152 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm2_loop_kernel: the NORM forms from ~100 rows on (decode steps of 64+ utterances, C4).  gemm2_kernel launches one
+// workgroup per (n-group, m-group): at 256 rows that is 1024 single-occupancy workgroups in four rounds, each of which streams its
+// weight tiles again (268 MB of L2 -> CU traffic per layer) and pays a cold start.  Here a workgroup OWNS an n-group: its weight
+// tiles are loaded once and stay in registers, and it walks the m-groups, the next group's activation rows in flight (asm loads)
+// while the current group runs on the matrix cores.  Same numbers: every (row, column) is computed exactly as in gemm2_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT, int EPI>
+__global__ __launch_bounds__(256) void gemm2_loop_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];      // [4 waves][MT][16 rows][512 B] | float [4][MT*16]
+    constexpr int KBS = 8, NW = 4, LPR = 32, RPI = 2, ABYTES = MT * KBS * 1024, TILES = MT * NT;
+    constexpr int NTO = (EPI == EPI_SILU) ? NT / 2 : NT, PIECES = MT * NTO * 64, PIT = (PIECES + 255) / 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int KB = a.K >> 5, kb0 = wave * KBS;
+    unsigned char* aimg = lds2 + (size_t)wave * ABYTES;
+    float* rowsum = reinterpret_cast<float*>(lds2 + (size_t)NW * ABYTES);
+    const int rsub = lane / LPR, ch = lane % LPR;
+    const int mgroups = ((a.M + 15) / 16 + MT - 1) / MT;
+    uint4_v ar[MT][KBS], wr[KBS][NT];
+    auto issue_a = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < KBS; ++t) {
+                int m = (g * MT + i) * 16 + t * RPI + rsub;
+                m = m < a.M ? m : a.M - 1;
+                gload16(ar[i][t], a.X + (size_t)m * a.K + kb0 * 32 + ch * 8);
+            }
+    };
+    auto stage_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < KBS; ++t) landed(ar[i][t]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < KBS; ++t)
+                *reinterpret_cast<uint4_v*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(t * RPI + rsub, ch)) = ar[i][t];
+        asm volatile("" ::: "memory");
+    };
+    auto group = [&](int g, auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        f32x4 acc[MT][NT], ss[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            ss[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        static_for([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            uint4 af[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(c, 4 * kb + q));
+            if constexpr (FIRST) {     // the weights land during the first group: younger = the later weight tiles + the next group's rows
+                wait_vmcnt<(KBS - 1 - kb) * NT + MT * KBS>();
+#pragma unroll
+                for (int t = 0; t < NT; ++t) landed(wr[kb][t]);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ss[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(af[i]), ss[i], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][t]), acc[i][t], 0, 0, 0);
+            }
+        }, std::make_integer_sequence<int, KBS>{});
+        asm volatile("" ::: "memory");
+        float* redw = reinterpret_cast<float*>(aimg);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) redw[((i * NT + t) * 4 + r) * 64 + lane] = acc[i][t][r];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int r = c & 3;
+            const float d = r == 0 ? ss[i][0] : r == 1 ? ss[i][1] : r == 2 ? ss[i][2] : ss[i][3];
+            if ((c >> 2) == q) rowsum[wave * (MT * 16) + i * 16 + c] = d;
+        }
+        __syncthreads();
+        auto part = [&](int w) { return reinterpret_cast<const float*>(lds2 + (size_t)w * ABYTES); };
+#pragma unroll
+        for (int k = 0; k < PIT; ++k) {
+            const int p = tid + k * 256;
+            if (p >= PIECES) continue;
+            const int ito = p >> 6, r16 = (p >> 2) & 15, qq = p & 3;
+            const int i = ito / NTO, to = ito % NTO;
+            const int m = (g * MT + i) * 16 + r16;
+            if (m >= a.M) continue;
+            const int gq = r16 >> 2, r = r16 & 3;
+            float v[EPI == EPI_SILU ? 2 : 1][4];
+#pragma unroll
+            for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u) {
+                const int it = i * NT + (EPI == EPI_SILU ? 2 * to + u : to);
+                const int o = (it * 4 + r) * 64 + 16 * gq + 4 * qq;
+                const float4 s0 = *reinterpret_cast<const float4*>(part(0) + o), s1 = *reinterpret_cast<const float4*>(part(1) + o),
+                             s2 = *reinterpret_cast<const float4*>(part(2) + o), s3 = *reinterpret_cast<const float4*>(part(3) + o);
+                v[u][0] = ((s0.x + s1.x) + s2.x) + s3.x; v[u][1] = ((s0.y + s1.y) + s2.y) + s3.y;
+                v[u][2] = ((s0.z + s1.z) + s2.z) + s3.z; v[u][3] = ((s0.w + s1.w) + s2.w) + s3.w;
+            }
+            const int rl = i * 16 + r16;
+            const float ssum = ((rowsum[rl] + rowsum[MT * 16 + rl]) + rowsum[2 * MT * 16 + rl]) + rowsum[3 * MT * 16 + rl];
+            const float rstd = 1.0f / sqrtf(ssum * (1.0f / 1024.0f) + 1e-5f);
+#pragma unroll
+            for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u][e] = v[u][e] * rstd;
+            const int n = (blockIdx.x * NTO + to) * 16 + 4 * qq;
+            if (n >= a.N) continue;
+            uint32_t ob[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ob[e] = (EPI == EPI_SILU) ? silu_mul_bf(f2bf(v[0][e]), f2bf(v[EPI == EPI_SILU ? 1 : 0][e])) : f2bf(v[0][e]);
+            uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
+            if (n + 3 < a.N || a.ldo >= ((a.N + 3) & ~3)) *reinterpret_cast<uint2*>(op) = make_uint2(ob[0] | (ob[1] << 16), ob[2] | (ob[3] << 16));
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n + e < a.N) op[e] = (uint16_t)ob[e];
+            }
+        }
+    };
+
+    // the m-groups are dealt round-robin over gridDim.y workgroups per n-group (two workgroups per CU overlap one's epilogue with
+    // the other's matrix work); the launcher guarantees every workgroup at least two groups
+    const int g0 = blockIdx.y, gs = gridDim.y;
+    issue_a(g0);
+#pragma unroll
+    for (int kb = 0; kb < KBS; ++kb)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gload16_nt(wr[kb][t], a.Wp + ((size_t)(blockIdx.x * NT + t) * KB + kb0 + kb) * 64 + lane);
+    wait_vmcnt<KBS * NT>();                        // the first group's rows are in (the weight tiles are younger)
+    stage_a();
+    issue_a(g0 + gs);
+    group(g0, std::true_type{});
+    for (int g = g0 + gs; g < mgroups; g += gs) {
+        __syncthreads();                           // every wave is done with the previous group's partials: the A images may be overwritten
+        wait_vmcnt<0>();                           // this group's rows (nothing younger is in flight)
+        stage_a();
+        if (g + gs < mgroups) issue_a(g + gs);
+        group(g, std::false_type{});
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Prefill-sized GEMM (M >= 256 rows): the same numbers as gemm_kernel, another schedule.  A workgroup of four waves owns a
 // 128-row x 64-column tile (4 packed n-tiles); every K step of 32 is staged once through LDS (activations 128 x 64 B row
 // pieces; weights: 4 packed 1 KiB fragments, the NORM forms' carrying the norm weight) and feeds 32 MFMAs, so a weight byte is
@@ -612,6 +758,28 @@ static hipError_t launch_gemm2_t(const GemmArgs* a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NW * 64), lds, s, *a);
     return hipGetLastError();
 }
+// looped NORM form (>= 4 m-groups of 32 rows, no row gather): one workgroup per n-group, weights stationary in registers
+template <int NT, int EPI>
+static hipError_t launch_gemm2_loop_t(const GemmArgs* a, hipStream_t s) {
+    constexpr size_t lds = (size_t)4 * 2 * 8 * 1024 + (size_t)4 * 2 * 16 * sizeof(float);
+    auto kern = gemm2_loop_kernel<2, NT, EPI>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    if (!a) return hipSuccess;
+    const int ntiles = (a->N + 15) / 16;
+    const int gx = (EPI == EPI_SILU) ? (ntiles + NT / 2 - 1) / (NT / 2) : (ntiles + NT - 1) / NT;
+    const int mgroups = ((a->M + 15) / 16 + 1) / 2;
+    static int split_env = -1;
+    if (split_env < 0) { const char* e = getenv("T3_GEMM_LOOP_SPLIT"); split_env = e ? atoi(e) : 0; }
+    int gy = split_env > 0 ? split_env : 2;
+    while (gy > 1 && mgroups / gy < 2) --gy;       // every workgroup walks at least two groups (it prefetches one ahead)
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), lds, s, *a);
+    return hipGetLastError();
+}
 // NORM forms (4 waves, K = 1024): MT in {1, 2}, NT in {1, 2, 3, 4}
 static hipError_t launch_gemm2_norm(const GemmArgs* a, int epi, int mt, int nt, hipStream_t s) {
 #define T3_G2(E, MTV, NTV) return launch_gemm2_t<MTV, NTV, E, 4, 8, true>(a, s)
@@ -641,6 +809,8 @@ hipError_t prepare_gemm2() {
     for (int epi : {EPI_F32, EPI_RESID})
         for (int kbs : {2, 8})
             if ((e = launch_gemm2_16(nullptr, epi, kbs, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<1, EPI_BF16>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<2, EPI_SILU>(nullptr, nullptr)) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -669,6 +839,16 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
         // (256 for gate/up).  A weight whose last tile is partial (the speech head: 513 tiles) takes part when its packed buffer
         // was padded to a multiple of the tile group (GemmArgs::packed_tiles).
         if (mt > 2) mt = 2;
+        {
+            // gate/up from ~130 rows on (decode steps of 65+ utterances, C4): a workgroup per (gate/up pair, half of the row groups)
+            // walks its 32-row groups with the pair's weight tiles stationary in registers.  Measured at 256 rows: 25.8 -> 18.9 us
+            // (two workgroups per n-group; one: 24.3, four: 21.0); at 128 rows 13.9 -> 13.3.  qkv loses with it (8.3 -> 12.7 us at 256
+            // rows: 32 KiB of weights per workgroup do not pay for the walk) and keeps the one-workgroup-per-tile schedule.
+            static int loop_min = -1;
+            if (loop_min < 0) { const char* e = getenv("T3_GEMM_LOOP_MIN_ROWS"); loop_min = e ? atoi(e) : 129; }
+            if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_SILU) return launch_gemm2_loop_t<2, EPI_SILU>(&a, s);
+            if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_BF16 && getenv("T3_GEMM_LOOP_QKV")) return launch_gemm2_loop_t<1, EPI_BF16>(&a, s);
+        }
         int nt = epi == EPI_SILU ? 2 : 1;
         if (epi != EPI_F32 && (!a.row_index || a.packed_tiles > 0)) {
             static int force = -1;

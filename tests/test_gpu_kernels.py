@@ -108,7 +108,7 @@ def test_gemm_wide_dynamic_range(E, oracle):
     assert_bit_equal(E.k_gemm(x, W), oracle.gemm(x, W), "gemm wide range")
 
 
-@pytest.mark.parametrize("M", [2, 40])
+@pytest.mark.parametrize("M", [2, 40, 97, 130, 256])        # 97+ rows: the weights-stationary looped schedule
 def test_gate_up_silu_bit_exact(E, oracle, M):
     Fd = 512
     h = rand_bf16(M, 1024, seed=1, scale=2.0); ln = (rand_bf16(1024, seed=8) + 1.0).to(torch.bfloat16)
