@@ -385,10 +385,11 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
 // tiles are loaded once and stay in registers, and it walks the m-groups, the next group's activation rows in flight (asm loads)
 // while the current group runs on the matrix cores.  Same numbers: every (row, column) is computed exactly as in gemm2_kernel.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, int EPI>
-__global__ __launch_bounds__(256) void gemm2_loop_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];      // [4 waves][MT][16 rows][512 B] | float [4][MT*16]
-    constexpr int KBS = 8, NW = 4, LPR = 32, RPI = 2, ABYTES = MT * KBS * 1024, TILES = MT * NT;
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
+__global__ __launch_bounds__(NW * 64) void gemm2_loop_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];      // [NW waves][MT][16 rows][KBS * 64 B] | NORM: float [NW][MT*16]
+    static_assert(NT <= KBS && (KBS == 8 || KBS == 2) && (NW == 4 || NW == 16) && (NW == 4 || (MT == 1 && NT == 1)), "gemm2_loop shapes");
+    constexpr int LPR = KBS * 4, RPI = 64 / LPR, ABYTES = MT * KBS * 1024, TILES = MT * NT;
     constexpr int NTO = (EPI == EPI_SILU) ? NT / 2 : NT, PIECES = MT * NTO * 64, PIT = (PIECES + 255) / 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void gemm2_loop_kernel(GemmArgs a) {
                 *reinterpret_cast<uint4_v*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(t * RPI + rsub, ch)) = ar[i][t];
         asm volatile("" ::: "memory");
     };
-    auto group = [&](int g, auto first_c) {
+    auto group = [&](int g, auto first_c, uint16_t hres) {
         constexpr bool FIRST = decltype(first_c)::value;
         f32x4 acc[MT][NT], ss[MT];
 #pragma unroll
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void gemm2_loop_kernel(GemmArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                ss[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(af[i]), ss[i], 0, 0, 0);
+                if constexpr (NORM) ss[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(af[i]), ss[i], 0, 0, 0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][t]), acc[i][t], 0, 0, 0);
@@ -455,14 +456,36 @@ __global__ __launch_bounds__(256) void gemm2_loop_kernel(GemmArgs a) {
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) redw[((i * NT + t) * 4 + r) * 64 + lane] = acc[i][t][r];
+        if constexpr (NORM) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int r = c & 3;
-            const float d = r == 0 ? ss[i][0] : r == 1 ? ss[i][1] : r == 2 ? ss[i][2] : ss[i][3];
-            if ((c >> 2) == q) rowsum[wave * (MT * 16) + i * 16 + c] = d;
+            for (int i = 0; i < MT; ++i) {
+                const int r = c & 3;
+                const float d = r == 0 ? ss[i][0] : r == 1 ? ss[i][1] : r == 2 ? ss[i][2] : ss[i][3];
+                if ((c >> 2) == q) rowsum[wave * (MT * 16) + i * 16 + c] = d;
+            }
         }
         __syncthreads();
         auto part = [&](int w) { return reinterpret_cast<const float*>(lds2 + (size_t)w * ABYTES); };
+        if constexpr (NW == 16) {
+            // 16 segments: one output per thread (256 of the 1024 threads), ((G0 + G1) + G2) + G3 with G = ((s0 + s1) + s2) + s3
+            if (tid < 256) {
+                const int r = (tid >> 6) & 3, l2 = tid & 63;
+                const int m = g * 16 + 4 * (l2 >> 4) + r, n = blockIdx.x * 16 + (l2 & 15);
+                if (m < a.M && n < a.N) {
+                    const int o = r * 64 + l2;
+                    float tot = 0.0f;
+#pragma unroll
+                    for (int gsum = 0; gsum < 4; ++gsum) {
+                        float s4 = part(4 * gsum)[o];
+                        s4 = s4 + part(4 * gsum + 1)[o]; s4 = s4 + part(4 * gsum + 2)[o]; s4 = s4 + part(4 * gsum + 3)[o];
+                        tot = gsum == 0 ? s4 : tot + s4;
+                    }
+                    if constexpr (EPI == EPI_F32) reinterpret_cast<float*>(a.out)[(size_t)m * a.ldo + n] = tot;
+                    else reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)f2bf(bf2f(hres) + rbf(tot));     // EPI_RESID
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < PIT; ++k) {
             const int p = tid + k * 256;
@@ -482,13 +505,15 @@ __global__ __launch_bounds__(256) void gemm2_loop_kernel(GemmArgs a) {
                 v[u][0] = ((s0.x + s1.x) + s2.x) + s3.x; v[u][1] = ((s0.y + s1.y) + s2.y) + s3.y;
                 v[u][2] = ((s0.z + s1.z) + s2.z) + s3.z; v[u][3] = ((s0.w + s1.w) + s2.w) + s3.w;
             }
-            const int rl = i * 16 + r16;
-            const float ssum = ((rowsum[rl] + rowsum[MT * 16 + rl]) + rowsum[2 * MT * 16 + rl]) + rowsum[3 * MT * 16 + rl];
-            const float rstd = 1.0f / sqrtf(ssum * (1.0f / 1024.0f) + 1e-5f);
+            if constexpr (NORM) {
+                const int rl = i * 16 + r16;
+                const float ssum = ((rowsum[rl] + rowsum[MT * 16 + rl]) + rowsum[2 * MT * 16 + rl]) + rowsum[3 * MT * 16 + rl];
+                const float rstd = 1.0f / sqrtf(ssum * (1.0f / 1024.0f) + 1e-5f);
 #pragma unroll
-            for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u)
+                for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[u][e] = v[u][e] * rstd;
+                    for (int e = 0; e < 4; ++e) v[u][e] = v[u][e] * rstd;
+            }
             const int n = (blockIdx.x * NTO + to) * 16 + 4 * qq;
             if (n >= a.N) continue;
             uint32_t ob[4];
@@ -506,6 +531,17 @@ __global__ __launch_bounds__(256) void gemm2_loop_kernel(GemmArgs a) {
     // the m-groups are dealt round-robin over gridDim.y workgroups per n-group (two workgroups per CU overlap one's epilogue with
     // the other's matrix work); the launcher guarantees every workgroup at least two groups
     const int g0 = blockIdx.y, gs = gridDim.y;
+    // EPI_RESID: the residual operand of a group is a compiler-counted load: requested before the asm loads of the first group (it
+    // must be the oldest there: the hand-counted waits assume only asm loads behind them), at the start of every later one
+    auto load_res = [&](int g) -> uint16_t {
+        if constexpr (EPI == EPI_RESID) {
+            const int r = (tid >> 6) & 3, l2 = tid & 63;
+            const int m = g * 16 + 4 * (l2 >> 4) + r, n = blockIdx.x * 16 + (l2 & 15);
+            if (tid < 256 && m < a.M && n < a.N) return reinterpret_cast<const uint16_t*>(a.out)[(size_t)m * a.ldo + n];
+        }
+        return 0;
+    };
+    uint16_t hres = load_res(g0);
     issue_a(g0);
 #pragma unroll
     for (int kb = 0; kb < KBS; ++kb)
@@ -514,13 +550,14 @@ __global__ __launch_bounds__(256) void gemm2_loop_kernel(GemmArgs a) {
     wait_vmcnt<KBS * NT>();                        // the first group's rows are in (the weight tiles are younger)
     stage_a();
     issue_a(g0 + gs);
-    group(g0, std::true_type{});
+    group(g0, std::true_type{}, hres);
     for (int g = g0 + gs; g < mgroups; g += gs) {
         __syncthreads();                           // every wave is done with the previous group's partials: the A images may be overwritten
         wait_vmcnt<0>();                           // this group's rows (nothing younger is in flight)
         stage_a();
+        hres = load_res(g);
         if (g + gs < mgroups) issue_a(g + gs);
-        group(g, std::false_type{});
+        group(g, std::false_type{}, hres);
     }
 }
 
@@ -759,12 +796,12 @@ static hipError_t launch_gemm2_t(const GemmArgs* a, hipStream_t s) {
     return hipGetLastError();
 }
 // looped NORM form (>= 4 m-groups of 32 rows, no row gather): one workgroup per n-group, weights stationary in registers
-template <int NT, int EPI>
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
 static hipError_t launch_gemm2_loop_t(const GemmArgs* a, hipStream_t s) {
-    constexpr size_t lds = (size_t)4 * 2 * 8 * 1024 + (size_t)4 * 2 * 16 * sizeof(float);
-    auto kern = gemm2_loop_kernel<2, NT, EPI>;
+    constexpr size_t lds = (size_t)NW * MT * KBS * 1024 + (NORM ? (size_t)NW * MT * 16 * sizeof(float) : 0);
+    auto kern = gemm2_loop_kernel<MT, NT, EPI, NW, KBS, NORM>;
     static bool raised = false;
-    if (!raised) {
+    if (!raised && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         raised = true;
@@ -772,12 +809,12 @@ static hipError_t launch_gemm2_loop_t(const GemmArgs* a, hipStream_t s) {
     if (!a) return hipSuccess;
     const int ntiles = (a->N + 15) / 16;
     const int gx = (EPI == EPI_SILU) ? (ntiles + NT / 2 - 1) / (NT / 2) : (ntiles + NT - 1) / NT;
-    const int mgroups = ((a->M + 15) / 16 + 1) / 2;
+    const int mgroups = ((a->M + 15) / 16 + MT - 1) / MT;
     static int split_env = -1;
-    if (split_env < 0) { const char* e = getenv("T3_GEMM_LOOP_SPLIT"); split_env = e ? atoi(e) : 0; }
-    int gy = split_env > 0 ? split_env : 2;
-    while (gy > 1 && mgroups / gy < 2) --gy;       // every workgroup walks at least two groups (it prefetches one ahead)
-    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), lds, s, *a);
+    if (split_env < 0) { const char* e = getenv(NW == 16 ? "T3_GEMM_LOOP16_SPLIT" : "T3_GEMM_LOOP_SPLIT"); split_env = e ? atoi(e) : 0; }
+    int gy = split_env > 0 ? split_env : (NW == 16 ? 4 : 2);
+    while (gy > 1 && mgroups / gy < (NW == 16 ? 1 : 2)) --gy;      // 4 waves: every workgroup walks at least two groups (16 waves: one is enough to win, measured)
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NW * 64), lds, s, *a);
     return hipGetLastError();
 }
 // NORM forms (4 waves, K = 1024): MT in {1, 2}, NT in {1, 2, 3, 4}
@@ -809,8 +846,10 @@ hipError_t prepare_gemm2() {
     for (int epi : {EPI_F32, EPI_RESID})
         for (int kbs : {2, 8})
             if ((e = launch_gemm2_16(nullptr, epi, kbs, nullptr)) != hipSuccess) return e;
-    if ((e = launch_gemm2_loop_t<1, EPI_BF16>(nullptr, nullptr)) != hipSuccess) return e;
-    if ((e = launch_gemm2_loop_t<2, EPI_SILU>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<2, 1, EPI_BF16, 4, 8, true>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<2, 2, EPI_SILU, 4, 8, true>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 8, false>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 2, false>(nullptr, nullptr)) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -846,8 +885,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             // rows: 32 KiB of weights per workgroup do not pay for the walk) and keeps the one-workgroup-per-tile schedule.
             static int loop_min = -1;
             if (loop_min < 0) { const char* e = getenv("T3_GEMM_LOOP_MIN_ROWS"); loop_min = e ? atoi(e) : 129; }
-            if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_SILU) return launch_gemm2_loop_t<2, EPI_SILU>(&a, s);
-            if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_BF16 && getenv("T3_GEMM_LOOP_QKV")) return launch_gemm2_loop_t<1, EPI_BF16>(&a, s);
+            if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_SILU) return launch_gemm2_loop_t<2, 2, EPI_SILU, 4, 8, true>(&a, s);
+            if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_BF16 && getenv("T3_GEMM_LOOP_QKV")) return launch_gemm2_loop_t<2, 1, EPI_BF16, 4, 8, true>(&a, s);
         }
         int nt = epi == EPI_SILU ? 2 : 1;
         if (epi != EPI_F32 && (!a.row_index || a.packed_tiles > 0)) {
@@ -868,6 +907,15 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             if (force >= 1 && force <= 4 && (epi != EPI_SILU || force % 2 == 0) && ntiles % force == 0) nt = force;
         }
         return launch_gemm2_norm(&a, epi, mt, nt, s);
+    }
+    if (nw == 16 && (a.K == D || a.K == F) && a.N % 16 == 0 && !a.row_index && epi == EPI_RESID) {
+        // o / down from 81 rows on (6+ m-tiles): a workgroup per (n-tile, quarter of the m-tiles) walks its m-tiles with the tile's
+        // weights stationary in registers (T3_GEMM_LOOP16_MIN_ROWS; 0 = off).  Measured, us per launch old -> looped: down 10.9 -> 8.3
+        // at 96 rows, 11.9 -> 8.5 at 128, 21.9 -> 10.2 at 192, 19.4 -> 11.9 at 256; o 7.5 -> 6.0 at 256; at 64 rows the old form wins
+        static int loop16_min = -1;
+        if (loop16_min < 0) { const char* e = getenv("T3_GEMM_LOOP16_MIN_ROWS"); loop16_min = e ? atoi(e) : 81; }
+        if (loop16_min > 0 && a.M >= loop16_min)
+            return a.K == D ? launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 2, false>(&a, s) : launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 8, false>(&a, s);
     }
     if (nw == 16 && mt == 1 && (a.K == D || a.K == F) && a.N % 16 == 0 && !a.row_index && (epi == EPI_F32 || epi == EPI_RESID))
         return launch_gemm2_16(&a, epi, a.K / 512, s);
