@@ -108,6 +108,7 @@ struct T3Engine {
     // One enqueued step: what the scheduler put on each group's stream, kept until its tokens are back.
     struct StepRec {
         int M = 0, n_sel = 0, n_prefill_rows = 0, decode_rows = 0;
+        int max_prefill_ctx = 0;       // longest context among the step's prefill rows (sizes the tile attention's LDS)
         double sum_ctx = 0;
         std::vector<Request*> sampled;
     };
@@ -529,7 +530,7 @@ static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec&
             HIP_TRY(launch_attention(aa, s));
         } else {
             { Prof p(e, K_ROPE, s); RopeArgs ra{g.qkv, g.qrot, kvL, g.dm.rows, e->row_stride, e->cos_t, e->sin_t, M}; HIP_TRY(launch_rope_kv(ra, s)); }
-            { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot, kvL, g.dm.rows, e->row_stride, g.att, M, max_chunks, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(launch_attention(aa, s)); }
+            { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot, kvL, g.dm.rows, e->row_stride, g.att, M, max_chunks, nullptr, nullptr, nullptr, nullptr, sr.n_prefill_rows > 0 ? sr.decode_rows : -1, (sr.max_prefill_ctx + CHUNK - 1) / CHUNK}; HIP_TRY(launch_attention(aa, s)); }
         }
         { Prof p(e, K_O, s); GemmArgs a{g.att, (const uint4*)y.o, M, D, D, g.h, D, 16, 0, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
         { Prof p(e, K_GU, s); GemmArgs a{g.h, (const uint4*)y.gu, M, D, F, g.act, F, 4, 1, nullptr, 0, g.rstd}; HIP_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s)); }
@@ -595,7 +596,7 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
                 else add_row(gi, 2 * r.slot + sI, p, EMB_SPEECH, 6561, 0);      // BOS: speech_emb[start] + speech_pos[0], t3.py:550-551
                 if (p == T - 1) hm.sel_rows[2 * sr.n_sel + sI] = sr.M - 1;
             }
-        r.n_prefilled = p1; sr.n_prefill_rows += 2 * chunk;
+        r.n_prefilled = p1; sr.n_prefill_rows += 2 * chunk; sr.max_prefill_ctx = std::max(sr.max_prefill_ctx, p1);
         if (p1 == T) {
             hm.sel[sr.n_sel] = make_int4(r.slot, 0, 0, 0);
             r.state = DECODE; r.n_sched = 1; r.last_idx = sr.n_sel;

@@ -134,7 +134,7 @@ extern "C" int t3k_rope_attention(const void* qkv, const int32_t* row_stream, co
     K_TRY(dq.alloc((size_t)rows * D * 2)); K_TRY(dkv.alloc((size_t)nb * KV_BLOCK_ELEMS * 2, true)); K_TRY(dout.alloc((size_t)rows * D * 2, true));
     RopeArgs ra{dqkv.as<uint16_t>(), dq.as<uint16_t>(), dkv.as<uint16_t>(), drec.as<int>(), stride, dc.as<float>(), ds.as<float>(), rows};
     K_TRY(launch_rope_kv(ra, nullptr));
-    AttnArgs aa{dq.as<uint16_t>(), dkv.as<uint16_t>(), drec.as<int>(), stride, dout.as<uint16_t>(), rows, (max_pos + CHUNK - 1) / CHUNK, nullptr, nullptr, nullptr, nullptr};
+    AttnArgs aa{dq.as<uint16_t>(), dkv.as<uint16_t>(), drec.as<int>(), stride, dout.as<uint16_t>(), rows, (max_pos + CHUNK - 1) / CHUNK, nullptr, nullptr, nullptr, nullptr, 0, 0};     // every row through the 16-row tile schedule
     K_TRY(launch_attention(aa, nullptr));
     K_TRY(hipDeviceSynchronize());
     K_TRY(hipMemcpy(out, dout.p, (size_t)rows * D * 2, hipMemcpyDeviceToHost));

@@ -88,6 +88,9 @@ struct AttnArgs {
     const uint16_t* qkv;       // [rows][3072] pre-RoPE, or null for the unfused form
     uint16_t* kv_layer_w;      // writable alias of kv_layer
     const float *cos_t, *sin_t;
+    // unfused form: rows [tile_from, rows) are prefill rows and take the 16-rows-per-workgroup schedule (-1: none); tile_chunks =
+    // ceil(longest context among them / 64) sizes its LDS (0: max_chunks)
+    int tile_from = -1, tile_chunks = 0;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 

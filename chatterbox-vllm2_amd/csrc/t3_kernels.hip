@@ -884,7 +884,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             // (two workgroups per n-group; one: 24.3, four: 21.0); at 128 rows 13.9 -> 13.3.  qkv loses with it (8.3 -> 12.7 us at 256
             // rows: 32 KiB of weights per workgroup do not pay for the walk) and keeps the one-workgroup-per-tile schedule.
             static int loop_min = -1;
-            if (loop_min < 0) { const char* e = getenv("T3_GEMM_LOOP_MIN_ROWS"); loop_min = e ? atoi(e) : 129; }
+            if (loop_min < 0) { const char* e = getenv("T3_GEMM_LOOP_MIN_ROWS"); loop_min = e ? atoi(e) : 81; }
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_SILU) return launch_gemm2_loop_t<2, 2, EPI_SILU, 4, 8, true>(&a, s);
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_BF16 && getenv("T3_GEMM_LOOP_QKV")) return launch_gemm2_loop_t<2, 1, EPI_BF16, 4, 8, true>(&a, s);
         }
@@ -1331,10 +1331,154 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
     }
     T3_ASTAMP(5);
 }
+// ------------------------------------------------------------------------------------------------
+// Prefill form of the same attention: one workgroup per (head, 16 consecutive rows of the launch).  The decode kernel replicates
+// one q over the 16 B-operand columns of the MFMA; here the 16 columns are 16 different rows (positions) of one stream, so a K/V
+// tile is read once per 16 rows instead of once per row.  An MFMA output column depends on its own B column only, so every
+// row's numbers are those of the per-row kernel: same score and P.V chains, the butterfly sum of the 64 probabilities rebuilt
+// level by level on the (token = 16 tt + 4 kg + r) register layout, per-chunk partials folded in ascending chunk order.
+// Rows of different streams in one tile (prompt boundaries, decode rows) are served segment by segment.
+// ------------------------------------------------------------------------------------------------
+constexpr int TILE_OS = 68;             // floats per (chunk, row) line of partial outputs (64 + padding against LDS bank conflicts)
+constexpr int TILE_PS = 72;             // bf16 per row of a wave's probability image (144 B: 16-byte aligned, conflict-free enough)
+__global__ __launch_bounds__(256, 2) void attention_tile_kernel(AttnArgs a, int row_base, int chunks_cap) {
+    extern __shared__ __attribute__((aligned(16))) float part[];   // [cap][16][TILE_OS] o | [cap][16] m | [cap][16] l | per wave: [16][TILE_PS] bf16 p
+    float* po = part; float* pm = part + (size_t)chunks_cap * 16 * TILE_OS; float* pl = pm + chunks_cap * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint16_t* pimg = reinterpret_cast<uint16_t*>(pl + chunks_cap * 16) + wave * (16 * TILE_PS);
+    const int col = lane & 15, kg = lane >> 4;
+    const int h = blockIdx.x, r0 = row_base + blockIdx.y * 16;
+    const int nrows = min(16, a.rows - r0);
+    const int myrow = r0 + min(col, nrows - 1);
+    const int* myrec = a.rowrec + (size_t)myrow * a.row_stride;
+    const int my_stream = myrec[0], my_L = myrec[1] + 1;
+    uint4 qfrag[2];                                 // B operand: column col = row r0 + col
+    {
+        const uint16_t* qsrc = a.q + (size_t)myrow * D + h * HD + kg * 8;
+        qfrag[0] = *reinterpret_cast<const uint4*>(qsrc); qfrag[1] = *reinterpret_cast<const uint4*>(qsrc + 32);
+    }
+    constexpr int CPB = KV_BLOCK / CHUNK;
+    const unsigned valid = nrows >= 16 ? 0xffffu : ((1u << nrows) - 1u);
+    unsigned done = 0;
+    while ((done & valid) != valid) {               // one pass per stream present in the tile (wave-uniform control flow)
+        const int lead = __builtin_ctz(~done & valid);
+        const int lead_stream = __builtin_amdgcn_readlane(my_stream, lead);
+        const bool in_seg = col < nrows && my_stream == lead_stream;
+        const unsigned seg = (unsigned)(__ballot(in_seg) & 0xffffull);
+        int Lmax = in_seg ? my_L : 0;
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, off));
+        Lmax = __builtin_amdgcn_readfirstlane(Lmax);
+        const int nc = min((Lmax + CHUNK - 1) / CHUNK, chunks_cap);
+        const int* bt = a.rowrec + (size_t)(r0 + lead) * a.row_stride + ROW_HDR;
+        for (int c = wave; c < nc; c += 4) {
+            uint4 kf[8], vf[8];
+            {
+                const int blk = bt[c / CPB], ci = c % CPB;
+                const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 0, h) + (size_t)ci * (CHUNK * HD)) + lane;
+                const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 1, h) + (size_t)ci * (CHUNK * HD)) + lane;
+#pragma unroll
+                for (int f = 0; f < 8; ++f) kf[f] = Kp[f * 64];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) vf[f] = Vp[f * 64];
+            }
+            f32x4 sacc[4];                          // sacc[tt][r] = score of token 16 tt + 4 kg + r of the chunk for row col
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                sacc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                sacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf[2 * tt]), as_frag(qfrag[0]), sacc[tt], 0, 0, 0);
+                sacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf[2 * tt + 1]), as_frag(qfrag[1]), sacc[tt], 0, 0, 0);
+            }
+            const int nlive = my_L - c * CHUNK;     // tokens of this chunk the row sees (causal), may be <= 0 or >= 64
+            float sc[4][4], m = -INFINITY;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sc[tt][r] = (16 * tt + 4 * kg + r) < nlive ? sacc[tt][r] * 0.125f : -INFINITY;
+                    m = fmaxf(m, sc[tt][r]);
+                }
+            m = fmaxf(m, lane_xor<16>(m, lane)); m = fmaxf(m, lane_xor<32>(m, lane));
+            float pr[4][4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[tt][r] = (16 * tt + 4 * kg + r) < nlive ? t3_expf(sc[tt][r] - m) : 0.0f;
+            // the contract's butterfly sum over the 64 tokens (partners t ^ 32, 16, 8, 4, 2, 1): bits 5, 4 of the token are tt,
+            // bits 3, 2 are kg (lane bits 5, 4), bits 1, 0 are r
+            float b4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4[r] = (pr[0][r] + pr[2][r]) + (pr[1][r] + pr[3][r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4[r] = b4[r] + lane_xor<32>(b4[r], lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4[r] = b4[r] + lane_xor<16>(b4[r], lane);
+            const float lsum = (b4[0] + b4[2]) + (b4[1] + b4[3]);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                uint32_t pk[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[r] = (pr[tt][r] < 0x1p-100f) ? 0u : (uint32_t)f2bf(pr[tt][r]);
+                *reinterpret_cast<uint2*>(pimg + col * TILE_PS + 16 * tt + 4 * kg) = make_uint2(pk[0] | (pk[1] << 16), pk[2] | (pk[3] << 16));
+            }
+            asm volatile("" ::: "memory");          // wave-private LDS exchange (a wave's DS operations execute in order)
+            uint4 pfrag[2];
+            pfrag[0] = *reinterpret_cast<const uint4*>(pimg + col * TILE_PS + 8 * kg);
+            pfrag[1] = *reinterpret_cast<const uint4*>(pimg + col * TILE_PS + 32 + 8 * kg);
+            asm volatile("" ::: "memory");
+            if (kg == 0) { pm[c * 16 + col] = m; pl[c * 16 + col] = lsum; }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 oacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                oacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf[2 * dt]), as_frag(pfrag[0]), oacc, 0, 0, 0);
+                oacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf[2 * dt + 1]), as_frag(pfrag[1]), oacc, 0, 0, 0);
+                *reinterpret_cast<float4*>(po + (size_t)(c * 16 + col) * TILE_OS + 16 * dt + 4 * kg) = make_float4(oacc[0], oacc[1], oacc[2], oacc[3]);
+            }
+        }
+        __syncthreads();
+        {   // fold: thread = (row, 4 dims), ascending chunk order over the row's own chunks
+            const int row = tid >> 4, d4 = (tid & 15) * 4;
+            if ((seg >> row) & 1u) {
+                const int L = a.rowrec[(size_t)(r0 + row) * a.row_stride + 1] + 1;
+                const int ncr = min((L + CHUNK - 1) / CHUNK, chunks_cap);
+                float M = -INFINITY;
+                for (int c = 0; c < ncr; ++c) M = fmaxf(M, pm[c * 16 + row]);
+                float l = 0.0f, o[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < ncr; ++c) {
+                    const float w = t3_expf(pm[c * 16 + row] - M);
+                    const float4 oc = *reinterpret_cast<const float4*>(po + (size_t)(c * 16 + row) * TILE_OS + d4);
+                    l = __builtin_fmaf(w, pl[c * 16 + row], l);
+                    o[0] = __builtin_fmaf(w, oc.x, o[0]); o[1] = __builtin_fmaf(w, oc.y, o[1]);
+                    o[2] = __builtin_fmaf(w, oc.z, o[2]); o[3] = __builtin_fmaf(w, oc.w, o[3]);
+                }
+                const uint32_t lo = (uint32_t)f2bf(o[0] / l) | ((uint32_t)f2bf(o[1] / l) << 16), hi = (uint32_t)f2bf(o[2] / l) | ((uint32_t)f2bf(o[3] / l) << 16);
+                *reinterpret_cast<uint2*>(a.out + (size_t)(r0 + row) * D + h * HD + d4) = make_uint2(lo, hi);
+            }
+        }
+        done |= seg;
+        if ((done & valid) != valid) __syncthreads();      // the next segment reuses the partial slots
+    }
+}
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
-    static int nw_env = -1, nt = 0;
-    if (nw_env < 0) { const char* e = getenv("T3_ATTN_WAVES"); nw_env = e ? atoi(e) : 0; const char* t = getenv("T3_ATTN_NT"); nt = t ? atoi(t) : 1; }
+    static int nw_env = -1, nt = 0, tile_on = 1;
+    if (nw_env < 0) { const char* e = getenv("T3_ATTN_WAVES"); nw_env = e ? atoi(e) : 0; const char* t = getenv("T3_ATTN_NT"); nt = t ? atoi(t) : 1; const char* p = getenv("T3_ATTN_TILE"); tile_on = p ? atoi(p) : 1; }
+    if (!a.qkv && tile_on && a.tile_from >= 0 && a.tile_from < a.rows) {
+        // unfused form: rows [tile_from, rows) are prefill rows (runs of consecutive positions of a stream): 16 rows per workgroup
+        const int cap = a.tile_chunks > 0 ? min(a.tile_chunks, a.max_chunks) : a.max_chunks;
+        const size_t lds_t = ((size_t)cap * 16 * (TILE_OS + 2)) * sizeof(float) + (size_t)4 * 16 * TILE_PS * 2;
+        static size_t raised = 64 * 1024;
+        if (lds_t > raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+            if (e != hipSuccess) return e;
+            raised = lds_t;
+        }
+        hipLaunchKernelGGL(attention_tile_kernel, dim3(H, (a.rows - a.tile_from + 15) / 16), dim3(256), lds_t, s, a, a.tile_from, cap);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || a.tile_from == 0) return e;
+        AttnArgs head = a; head.rows = a.tile_from; head.tile_from = -1;
+        return launch_attention(head, s);
+    }
     // 4 waves per (row, head) fill the chip from 16 rows on (16 heads x 16 rows x 4 waves = 4 waves per CU); below that the
     // launch is latency-bound and 8 waves halve the number of sequential 64-token chunks per wave (B = 1: 2 rows -> 32 workgroups)
     const int nw = nw_env == 4 || nw_env == 8 ? nw_env : (a.rows <= 8 ? 8 : 4);
