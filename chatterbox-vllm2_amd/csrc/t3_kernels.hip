@@ -1066,6 +1066,38 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(RopeArgs a) {
     uint16_t* kb = a.kv_layer + kv_head_base(blk, 0, h);
     *reinterpret_cast<uint4*>(kb + k_slot(tok, 0, part)) = o1;       // dims 8*part..   -> ds 0, kg = part
     *reinterpret_cast<uint4*>(kb + k_slot(tok, 1, part)) = o2;       // dims 32+8*part.. -> ds 1, kg = part
+    // V is stored token-minor (8 consecutive tokens of one dim = 16 bytes, the MFMA A operand of P.V).  Prefill rows come as runs of
+    // consecutive positions: where the launch holds all 8 rows of an aligned token group, the wave of the group's first row
+    // transposes the 8 x 1024 block in registers and writes whole 16-byte pieces (128 contiguous bytes per lane); the other seven
+    // waves skip V.  Anything else (decode rows, ragged ends of a run) keeps the element-wise writes.
+    const int p8 = pos & 7, jl = row - p8;
+    bool full = false;
+    if (jl >= 0 && jl + 7 < a.rows) {
+        int ok = 1;
+        if (lane < 8) { const int* r2 = a.rowrec + (size_t)(jl + lane) * a.row_stride; ok = (r2[0] == rec[0]) && (r2[1] == pos - p8 + lane); }
+        full = __all(ok);
+    }
+    if (full) {
+        if (p8 != 0) return;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pc = lane + 64 * u, hh = pc >> 3, oct = pc & 7;          // (head, 8 dims 8 oct .. 8 oct + 7)
+            uint4 x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const uint4*>(a.qkv + (size_t)(row + i) * QKV + 2 * D + hh * 64 + oct * 8);
+            uint4* dst = reinterpret_cast<uint4*>(a.kv_layer + kv_head_base(blk, 1, hh) + v_elem(tok, oct * 8));
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const uint32_t sel = (d & 1) ? 0x07060302u : 0x05040100u;     // high or low halves of (second, first) operand
+                auto w = [&](const uint4& v) { return (d >> 1) == 0 ? v.x : (d >> 1) == 1 ? v.y : (d >> 1) == 2 ? v.z : v.w; };
+                uint4 y;
+                y.x = __builtin_amdgcn_perm(w(x[1]), w(x[0]), sel); y.y = __builtin_amdgcn_perm(w(x[3]), w(x[2]), sel);
+                y.z = __builtin_amdgcn_perm(w(x[5]), w(x[4]), sel); y.w = __builtin_amdgcn_perm(w(x[7]), w(x[6]), sel);
+                dst[d] = y;
+            }
+        }
+        return;
+    }
     uint16_t* vb = a.kv_layer + kv_head_base(blk, 1, h);
     const uint16_t* vs = qr + 2 * D + h * 64 + part * 16;
 #pragma unroll
