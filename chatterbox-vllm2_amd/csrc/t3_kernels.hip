@@ -864,8 +864,12 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
         // rows from which the LDS-tiled schedule takes over (0 = never).  1024: a 256-row call is a DECODE step of 128 utterances,
         // where 128 x 64 tiles leave 32-128 workgroups (measured on the continuous-batching run of tools/bench_serving.py:
         // 16.8 k tok/s with the switch at 256 rows, 25.0 k at 1024 or 2048).
-        if (g_pgemm_min_rows < 0) { const char* e = getenv("T3_PGEMM_MIN_ROWS"); g_pgemm_min_rows = e ? atoi(e) : 1024; }
-        const int pg_min = g_pgemm_min_rows;
+        // Per form since the looped schedules exist (tools/chain_proto at 320-1023 rows, us per launch looped | LDS-tiled: gate/up
+        // 24.9 | 25.8 at 384 rows, 30.6 | 28.6 at 512; qkv 16.8 | 22.0 at 512, 25.4 | 23.6 at 768; o 17.0 | 20.4 and down 34.1 | 46.5
+        // at 1023: the 16-segment fold of a 128 x 64 tile is a fixed ~18 / ~40 us): -2 = these per-form switches.
+        if (g_pgemm_min_rows == -1) { const char* e = getenv("T3_PGEMM_MIN_ROWS"); g_pgemm_min_rows = e ? atoi(e) : -2; }
+        const int pg_min = g_pgemm_min_rows != -2 ? g_pgemm_min_rows
+                         : epi == EPI_SILU ? 448 : (nw == 4 ? (a.row_index ? 1024 : 704) : (a.K == D ? 1280 : 1600));
         if (pg_min > 0 && a.M >= pg_min) {
             const hipError_t pe = launch_pgemm(a, epi, s);
             if (pe != hipErrorNotSupported) return pe;

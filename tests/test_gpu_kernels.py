@@ -72,7 +72,7 @@ def test_norm_folded_gemm_bit_exact(E, oracle, M, N):
 def test_prefill_sized_gemms_bit_exact(E, oracle, M):
     """The LDS-tiled prefill schedule (pgemm_kernel, 128 x 64 workgroup tiles, row statistic in its own pass) must not
     change the numbers: every form against the same oracle functions, ragged row counts."""
-    E.k_set_prefill_rows(256)                        # the engine switches at 1024 rows; here the schedule is checked on small cases
+    E.k_set_prefill_rows(256)                        # the engine switches per form at 448-1600 rows; here the schedule is checked on small cases
     try:
         _prefill_sized_checks(E, oracle, M)
     finally:
