@@ -33,6 +33,7 @@ bool have_device() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n 
 #define K_TRY(expr) do { if ((expr) != hipSuccess) return T3_E_DEVICE; } while (0)
 
 extern "C" int t3k_set_prefill_rows(int32_t rows) { set_pgemm_min_rows(rows); return T3_OK; }
+extern "C" int t3k_set_prefill_wide_rows(int32_t rows) { set_pgemm_wide_rows(rows); return T3_OK; }
 
 extern "C" int t3k_gemm(const void* x, const void* w, int32_t M, int32_t K, int32_t N, float* out, int32_t mt, int32_t nw) {
     if (!x || !w || !out || M <= 0 || N <= 0 || (nw != 4 && nw != 16) || K % (32 * nw)) return T3_E_INVALID;

@@ -48,6 +48,7 @@ void fold_norm_weight(const uint16_t* W, int N, int K, const uint16_t* ln, uint1
 int choose_mt(int M, int ntiles_x, int nw = 4, bool norm = false);
 hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s);
 void set_pgemm_min_rows(int rows);   // row count from which launch_gemm takes the prefill schedule (process-wide; < 0 = default)
+void set_pgemm_wide_rows(int rows);  // row count from which its 4-segment forms take 128 x 128 tiles (0 = never; < 0 = default 2048)
 
 // Per-row record of a step (int32 words), built by the scheduler and uploaded once per step:
 //   [0] stream  [1] position  [2] embed kind  [3] embed a  [4] embed b  [5..7] unused  [8 ..] KV block ids of the row's stream

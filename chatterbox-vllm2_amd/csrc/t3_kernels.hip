@@ -604,20 +604,26 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
-template <int EPI, int NSEG, bool NORM>
-__global__ __launch_bounds__(256, NSEG == 4 ? 4 : 3) void pgemm_kernel(GemmArgs a, const float* rstd) {
+// WC = packed n-tiles per wave: 2 (workgroup tile 128 x 64) or 4 (128 x 128: a fragment read from LDS feeds twice the MFMAs and a
+// weight / activation byte leaves L2 1.5 times less often; two accumulator sets of 64 registers, two workgroups per CU)
+template <int EPI, int NSEG, bool NORM, int WC>
+__global__ __launch_bounds__(256, WC == 4 ? 2 : (NSEG == 4 ? 4 : 3)) void pgemm_kernel(GemmArgs a, const float* rstd) {
     // Operand ring in LDS, filled by LDS-DMA three K steps ahead of the MFMAs (no staging registers: the global-load latency of
     // a step is covered by three steps of arithmetic instead of one).  Per stage: A image 128 rows x 64 B (swizzled, below) | 4
     // weight fragments x 1 KiB.  The NORM forms' activations go in untouched (the norm weight lives in the packed matrix).
 #ifndef T3_PGEMM_NS
 #define T3_PGEMM_NS 3      // measured at 8192 rows: 3 stages (36 KiB, 4 workgroups per CU) 214 / 92 / 91 us (gate-up / o+down / qkv), 4 stages 235 / 91 / 99, 6 stages 296 / 96 / 121
 #endif
-    constexpr int NS = T3_PGEMM_NS, AHEAD = NS - 1, STAGE = 768;               // stages in the ring; uint4 per stage
+#ifndef T3_PGEMM_NS_WIDE
+#define T3_PGEMM_NS_WIDE 3
+#endif
+    constexpr int NS = WC == 4 ? T3_PGEMM_NS_WIDE : T3_PGEMM_NS, AHEAD = NS - 1, NTW = 2 * WC, STAGE = 512 + NTW * 64;     // stages in the ring; n-tiles per workgroup; uint4 per stage
+    constexpr int PP = 2 + NTW / 4;                                              // DMA pieces per wave and stage
     __shared__ __attribute__((aligned(16))) uint4 ring[NS * STAGE];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 1, wc = wave & 1;                                   // wave tile: rows 64 wr .., packed n-tiles 2 wc, 2 wc + 1
     const int KB = a.K >> 5, kbs = KB / NSEG;
-    const int m0 = blockIdx.y * 128, nt0 = blockIdx.x * 4;
+    const int m0 = blockIdx.y * 128, nt0 = blockIdx.x * NTW;
     // A image: 64-byte rows, so four rows share a 256-byte bank row and the 16 rows of a fragment read would hit 4 bank slots.
     // Chunk q of row r sits at position ((r >> 2) & 3) ^ T[q], T = {0, 3, 2, 1} (an involution): the 16 lanes of each hardware
     // lane group of ds_read_b128 then land on 16 different slots.  A DMA piece writes LDS linearly, so the permutation is applied
@@ -631,17 +637,18 @@ __global__ __launch_bounds__(256, NSEG == 4 ? 4 : 3) void pgemm_kernel(GemmArgs 
     }
     const uint4* wsrc = a.Wp + ((size_t)(nt0 + wave) * KB) * 64 + lane;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
-    auto issue = [&](int kb) {                                                 // three 1 KiB pieces per wave and stage
+    auto issue = [&](int kb) {                                                 // PP 1 KiB pieces per wave and stage
         const unsigned base = lds0 + (unsigned)(((kb % NS) * STAGE + wave * 64) * 16);
         glds16(xsrc[0] + kb * 32, base);
         glds16(xsrc[1] + kb * 32, base + 256 * 16);
-        glds16(wsrc + (size_t)kb * 64, base + 512 * 16);
+#pragma unroll
+        for (int j = 0; j < NTW / 4; ++j) glds16(wsrc + ((size_t)(4 * j) * KB + kb) * 64, base + (512 + 256 * j) * 16);
     };
-    f32x4 sg[4][2], gr[4][2], tot[4][2];
+    f32x4 sg[4][WC], gr[4][WC], tot[4][NSEG > 4 ? WC : 1];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { sg[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f}; gr[i][u] = sg[i][u]; tot[i][u] = sg[i][u]; }
+        for (int u = 0; u < WC; ++u) { sg[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f}; gr[i][u] = sg[i][u]; if (NSEG > 4) tot[i][u] = sg[i][u]; }
 
 #pragma unroll
     for (int k0 = 0; k0 < AHEAD; ++k0) if (k0 < KB) issue(k0);
@@ -653,36 +660,36 @@ __global__ __launch_bounds__(256, NSEG == 4 ? 4 : 3) void pgemm_kernel(GemmArgs 
         const int younger = KB - 1 - kb < AHEAD - 1 ? KB - 1 - kb : AHEAD - 1;      // stages behind this one that may still be in flight
         switch (younger) {
             case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(15) lgkmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PP) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PP) : "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * PP) : "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * PP) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(5 * PP) : "memory"); break;
         }
         __builtin_amdgcn_s_barrier();
         const uint4* As = ring + (kb % NS) * STAGE;
         const uint4* Bs = As + 512;
-        uint4 af[4], bf[2];
+        uint4 af[4], bf[WC];
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = As[pgemm_a_pos(wr * 64 + i * 16 + (lane & 15), lane >> 4)];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) bf[u] = Bs[(wc * 2 + u) * 64 + lane];
+        for (int u = 0; u < WC; ++u) bf[u] = Bs[(wc * WC + u) * 64 + lane];
         if (kb + AHEAD < KB) issue(kb + AHEAD);          // into the buffer of step kb - 1: every wave is past its reads (barrier above)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < WC; ++u)
                 sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(bf[u]), sg[i][u], 0, 0, 0);
         if (++kin == kbs) {                      // segment complete: fold it
             const bool first_in_group = (seg & 3) == 0, last_in_group = (seg & 3) == 3;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < WC; ++u) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         gr[i][u][r] = first_in_group ? sg[i][u][r] : gr[i][u][r] + sg[i][u][r];
-                        if (NSEG > 4 && last_in_group) tot[i][u][r] = seg == 3 ? gr[i][u][r] : tot[i][u][r] + gr[i][u][r];
+                        if constexpr (NSEG > 4) { if (last_in_group) tot[i][u][r] = seg == 3 ? gr[i][u][r] : tot[i][u][r] + gr[i][u][r]; }
                         sg[i][u][r] = 0.0f;
                     }
                 }
@@ -696,17 +703,24 @@ __global__ __launch_bounds__(256, NSEG == 4 ? 4 : 3) void pgemm_kernel(GemmArgs 
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + wr * 64 + i * 16 + 4 * (lane >> 4) + r;
             if (m >= a.M) continue;
-            float v[2];
+            float v[WC];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) v[u] = NSEG > 4 ? tot[i][u][r] : gr[i][u][r];
-            if constexpr (NORM) { const float rs = rstd[m]; v[0] = v[0] * rs; v[1] = v[1] * rs; }
+            for (int u = 0; u < WC; ++u) { if constexpr (NSEG > 4) v[u] = tot[i][u][r]; else v[u] = gr[i][u][r]; }
+            if constexpr (NORM) {
+                const float rs = rstd[m];
+#pragma unroll
+                for (int u = 0; u < WC; ++u) v[u] = v[u] * rs;
+            }
             if constexpr (EPI == EPI_SILU) {
-                const int n = ((nt0 >> 1) + wc) * 16 + (lane & 15);          // packed pair (gate, up) -> one output tile
-                if (n < a.N) reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)silu_mul_bf(f2bf(v[0]), f2bf(v[1]));
+#pragma unroll
+                for (int u = 0; u < WC; u += 2) {                             // packed pair (gate, up) -> one output tile
+                    const int n = ((nt0 + wc * WC + u) >> 1) * 16 + (lane & 15);
+                    if (n < a.N) reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)silu_mul_bf(f2bf(v[u]), f2bf(v[u + 1]));
+                }
             } else {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int n = (nt0 + wc * 2 + u) * 16 + (lane & 15);
+                for (int u = 0; u < WC; ++u) {
+                    const int n = (nt0 + wc * WC + u) * 16 + (lane & 15);
                     if (n >= a.N) continue;
                     if constexpr (EPI == EPI_F32) {
                         reinterpret_cast<float*>(a.out)[(size_t)m * a.ldo + n] = v[u];
@@ -721,8 +735,9 @@ __global__ __launch_bounds__(256, NSEG == 4 ? 4 : 3) void pgemm_kernel(GemmArgs 
     }
 }
 
-static int g_pgemm_min_rows = -1;
+static int g_pgemm_min_rows = -1, g_pgemm_wide_rows = -1;
 void set_pgemm_min_rows(int rows) { g_pgemm_min_rows = rows; }
+void set_pgemm_wide_rows(int rows) { g_pgemm_wide_rows = rows; }
 
 // Large-M path of launch_gemm: returns hipErrorNotSupported when the shape is not one of the layer forms.
 static hipError_t launch_pgemm(const GemmArgs& a, int epi, hipStream_t s) {
@@ -730,19 +745,29 @@ static hipError_t launch_pgemm(const GemmArgs& a, int epi, hipStream_t s) {
     const int nseg = a.nw == 16 ? 16 : 4;
     const int ntiles = (a.N + 15) / 16 * (epi == EPI_SILU ? 2 : 1);
     if (a.row_index || ntiles % 4 || a.K % (32 * nseg) || (norm && (!a.rstd_scratch || a.K != D))) return hipErrorNotSupported;
-    const dim3 grid(ntiles / 4, (a.M + 127) / 128);
+    // 128 x 128 tiles for the 4-segment forms from 2048 rows on only with T3_PGEMM_WC=4 (or the parity tests' hook): measured at
+    // 8 178 rows x 30 layers, a prefill step takes 18.35 ms with 128 x 64 tiles, 18.76 with 128 x 128 and a 3-stage ring, 19.07
+    // with a 4-stage ring -- the two workgroups per CU that fit hide less latency than the four of the narrow form
+    static int wc_env = -1;
+    if (wc_env < 0) { const char* e = getenv("T3_PGEMM_WC"); wc_env = e ? atoi(e) : 2; }
+    const int wide_rows = g_pgemm_wide_rows >= 0 ? g_pgemm_wide_rows : 2048;          // 0 = never
+    const bool wide = (wc_env == 4 || g_pgemm_wide_rows > 0) && nseg == 4 && ntiles % 8 == 0 && wide_rows > 0 && a.M >= wide_rows;
+    const dim3 grid(ntiles / (wide ? 8 : 4), (a.M + 127) / 128);
+#define T3_PG(E, SEG, NRM, RS) do { if (wide) hipLaunchKernelGGL((pgemm_kernel<E, SEG, NRM, 4>), grid, dim3(256), 0, s, a, (const float*)(RS)); \
+                                    else hipLaunchKernelGGL((pgemm_kernel<E, SEG, NRM, 2>), grid, dim3(256), 0, s, a, (const float*)(RS)); } while (0)
     if (norm) {
         hipLaunchKernelGGL(row_rstd_kernel, dim3((a.M + 63) / 64), dim3(256), 0, s, a.X, a.rstd_scratch, a.M);
-        if (epi == EPI_BF16) hipLaunchKernelGGL((pgemm_kernel<EPI_BF16, 4, true>), grid, dim3(256), 0, s, a, (const float*)a.rstd_scratch);
-        else if (epi == EPI_F32) hipLaunchKernelGGL((pgemm_kernel<EPI_F32, 4, true>), grid, dim3(256), 0, s, a, (const float*)a.rstd_scratch);
-        else if (epi == EPI_SILU) hipLaunchKernelGGL((pgemm_kernel<EPI_SILU, 4, true>), grid, dim3(256), 0, s, a, (const float*)a.rstd_scratch);
+        if (epi == EPI_BF16) T3_PG(EPI_BF16, 4, true, a.rstd_scratch);
+        else if (epi == EPI_F32) T3_PG(EPI_F32, 4, true, a.rstd_scratch);
+        else if (epi == EPI_SILU) T3_PG(EPI_SILU, 4, true, a.rstd_scratch);
         else return hipErrorNotSupported;
     } else {
-        if (epi == EPI_RESID && nseg == 16) hipLaunchKernelGGL((pgemm_kernel<EPI_RESID, 16, false>), grid, dim3(256), 0, s, a, (const float*)nullptr);
-        else if (epi == EPI_F32 && nseg == 16) hipLaunchKernelGGL((pgemm_kernel<EPI_F32, 16, false>), grid, dim3(256), 0, s, a, (const float*)nullptr);
-        else if (epi == EPI_F32) hipLaunchKernelGGL((pgemm_kernel<EPI_F32, 4, false>), grid, dim3(256), 0, s, a, (const float*)nullptr);
+        if (epi == EPI_RESID && nseg == 16) hipLaunchKernelGGL((pgemm_kernel<EPI_RESID, 16, false, 2>), grid, dim3(256), 0, s, a, (const float*)nullptr);
+        else if (epi == EPI_F32 && nseg == 16) hipLaunchKernelGGL((pgemm_kernel<EPI_F32, 16, false, 2>), grid, dim3(256), 0, s, a, (const float*)nullptr);
+        else if (epi == EPI_F32) T3_PG(EPI_F32, 4, false, nullptr);
         else return hipErrorNotSupported;
     }
+#undef T3_PG
     return hipGetLastError();
 }
 

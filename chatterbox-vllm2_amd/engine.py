@@ -64,7 +64,7 @@ ABI_SYMBOLS = [
     "t3_clean_tokens", "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_set_profile_kernel", "t3_kernel_ms",
     "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_sample", "t3k_expf",
     "t3_cond_create", "t3_cond_destroy", "t3_cond_last_error", "t3_cond_load_tensor", "t3_cond_encode", "t3_cond_emotion_row",
-    "t3k_ce_layernorm", "t3k_ce_linear", "t3k_ce_attention", "t3k_set_prefill_rows",
+    "t3k_ce_layernorm", "t3k_ce_linear", "t3k_ce_attention", "t3k_set_prefill_rows", "t3k_set_prefill_wide_rows",
 ]
 
 KERNEL_CLASSES = ["gemm_qkv", "gemm_o", "gemm_gateup", "gemm_down", "gemm_head", "attention",
@@ -130,6 +130,7 @@ def load_library():
     L.t3k_ce_linear.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32]
     L.t3k_ce_attention.argtypes = [vp, vp, vp, vp, i32, i32]
     L.t3k_set_prefill_rows.argtypes = [i32]
+    L.t3k_set_prefill_wide_rows.argtypes = [i32]
     for s in ABI_SYMBOLS:
         if s not in ("t3_last_error", "t3_cond_last_error"):
             getattr(L, s).restype = ct.c_int
@@ -405,6 +406,8 @@ def k_ce_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.T
     return out
 
 
-def k_set_prefill_rows(rows: int) -> None:
-    """Process-wide: row count from which GEMM launches take the prefill schedule (< 0: default)."""
+def k_set_prefill_rows(rows: int, wide_rows: int = -1) -> None:
+    """Process-wide: row count from which GEMM launches take the prefill schedule (< 0: default), and from which its 4-segment
+    forms take 128 x 128 tiles (0: never, < 0: default)."""
     load_library().t3k_set_prefill_rows(int(rows))
+    load_library().t3k_set_prefill_wide_rows(int(wide_rows))

@@ -222,8 +222,11 @@ int t3k_expf(const float* x, float* y, int32_t n);
 /* the hand-off kernel on host buffers (one utterance): out [ld] padded with 0, *len = kept tokens */
 int t3k_handoff(const int32_t* speech_ids, int32_t n, int32_t text_token_count, int32_t flags, int32_t* out, int32_t ld, int32_t* len);
 /* Row count from which the GEMM launcher switches to its prefill schedule (same numbers, LDS-tiled); process-wide.
- * < 0 restores the default (1024).  For the parity tests, which check the prefill schedule at small row counts. */
+ * < 0 restores the default (per form, 448-1600 rows).  For the parity tests, which check the prefill schedule at small row counts. */
 int t3k_set_prefill_rows(int32_t rows);
+/* Row count from which the 4-segment forms of that schedule take 128 x 128 workgroup tiles instead of 128 x 64 (0 = never,
+ * < 0 = default 2048).  Same purpose. */
+int t3k_set_prefill_wide_rows(int32_t rows);
 
 #ifdef __cplusplus
 }

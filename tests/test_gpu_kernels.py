@@ -68,11 +68,11 @@ def test_norm_folded_gemm_bit_exact(E, oracle, M, N):
     assert (got.double() - ref).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("M", [256, 300, 515])
-def test_prefill_sized_gemms_bit_exact(E, oracle, M):
-    """The LDS-tiled prefill schedule (pgemm_kernel, 128 x 64 workgroup tiles, row statistic in its own pass) must not
-    change the numbers: every form against the same oracle functions, ragged row counts."""
-    E.k_set_prefill_rows(256)                        # the engine switches per form at 448-1600 rows; here the schedule is checked on small cases
+@pytest.mark.parametrize("M,wide", [(256, 0), (300, 0), (515, 0), (256, 256), (300, 256), (515, 256)])
+def test_prefill_sized_gemms_bit_exact(E, oracle, M, wide):
+    """The LDS-tiled prefill schedule (pgemm_kernel, 128 x 64 or 128 x 128 workgroup tiles, row statistic in its own pass) must
+    not change the numbers: every form against the same oracle functions, ragged row counts."""
+    E.k_set_prefill_rows(256, wide)                        # the engine switches per form at 448-1600 rows; here the schedule is checked on small cases
     try:
         _prefill_sized_checks(E, oracle, M)
     finally:
