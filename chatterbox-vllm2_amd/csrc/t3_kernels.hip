@@ -674,12 +674,21 @@ __global__ __launch_bounds__(256, WC == 4 ? 2 : (NSEG == 4 ? 4 : 3)) void pgemm_
         for (int i = 0; i < 4; ++i) af[i] = As[pgemm_a_pos(wr * 64 + i * 16 + (lane & 15), lane >> 4)];
 #pragma unroll
         for (int u = 0; u < WC; ++u) bf[u] = Bs[(wc * WC + u) * 64 + lane];
+#ifndef T3_PGEMM_NODMA       // diagnostic builds only: which resource bounds the schedule
         if (kb + AHEAD < KB) issue(kb + AHEAD);          // into the buffer of step kb - 1: every wave is past its reads (barrier above)
+#endif
+#ifdef T3_PGEMM_NOMFMA
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < WC; ++u) { sg[i][u][0] += __uint_as_float(af[i].x ^ bf[u].y); sg[i][u][1] += __uint_as_float(af[i].z ^ bf[u].w); }
+#else
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int u = 0; u < WC; ++u)
                 sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(bf[u]), sg[i][u], 0, 0, 0);
+#endif
         if (++kin == kbs) {                      // segment complete: fold it
             const bool first_in_group = (seg & 3) == 0, last_in_group = (seg & 3) == 3;
 #pragma unroll
