@@ -121,6 +121,7 @@ struct T3Engine {
     std::vector<Group> groups;
     unsigned step_seq = 0;
     bool run_ahead = true;     // t3_run_steps / t3_run_until_done enqueue step N+1 before reading step N's tokens
+    int64_t graph_captures = 0; double graph_capture_ms = 0;      // T3_GRAPH_STATS=1 prints them at destroy
     std::chrono::steady_clock::time_point t_last_complete{};
     float* d_cond = nullptr;
     uint16_t* d_counts = nullptr;
@@ -201,6 +202,7 @@ extern "C" int t3_destroy(T3Handle e) {
     if (!e) return T3_E_INVALID;
     (void)hipSetDevice(e->cfg.device_id);
     (void)hipStreamSynchronize(e->stream);
+    if (getenv("T3_GRAPH_STATS")) fprintf(stderr, "[t3] decode-step graphs captured: %lld, %.1f ms in capture + instantiate\n", (long long)e->graph_captures, e->graph_capture_ms);
     for (auto& L : e->layers) { free_dev(L.qkv); free_dev(L.o); free_dev(L.gu); free_dev(L.down); }
     free_dev(e->text_emb); free_dev(e->speech_emb); free_dev(e->text_pos); free_dev(e->speech_pos); free_dev(e->head);
     free_dev(e->cos_t); free_dev(e->sin_t); free_dev(e->kv); free_dev(e->d_block_table);
@@ -523,11 +525,20 @@ static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec&
         uint16_t* kvL = e->kv + (size_t)L * layer_elems;
         // 5 launches per layer: RMSNorm is folded into the qkv / gate-up GEMMs, the residual add into the o / down GEMMs
         { Prof p(e, K_QKV, s); GemmArgs a{g.h, (const uint4*)y.qkv, M, D, QKV, g.qkv, QKV, 4, 1, nullptr, 0, g.rstd}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s)); }
-        if (sr.n_prefill_rows == 0 && e->fuse_rope) {
-            // decode-only step: every row is the newest position of its stream -> RoPE + KV write inside the attention kernel
-            Prof p(e, K_ATTN, s);
-            AttnArgs aa{nullptr, kvL, g.dm.rows, e->row_stride, g.att, M, max_chunks, g.qkv, kvL, e->cos_t, e->sin_t};
-            HIP_TRY(launch_attention(aa, s));
+        const int dec = sr.n_prefill_rows > 0 ? sr.decode_rows : M;      // decode rows come first in the step's row list
+        if (e->fuse_rope) {
+            // decode rows: every one is the newest position of its stream -> RoPE + KV write inside the attention kernel
+            if (dec > 0) {
+                Prof p(e, K_ATTN, s);
+                AttnArgs aa{nullptr, kvL, g.dm.rows, e->row_stride, g.att, dec, max_chunks, g.qkv, kvL, e->cos_t, e->sin_t};
+                HIP_TRY(launch_attention(aa, s));
+            }
+            // prefill rows (runs of consecutive positions): RoPE + paged KV write, then the 16-rows-per-workgroup attention
+            if (M > dec) {
+                const int* rows_p = g.dm.rows + (size_t)dec * e->row_stride;
+                { Prof p(e, K_ROPE, s); RopeArgs ra{g.qkv + (size_t)dec * QKV, g.qrot + (size_t)dec * D, kvL, rows_p, e->row_stride, e->cos_t, e->sin_t, M - dec}; HIP_TRY(launch_rope_kv(ra, s)); }
+                { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot + (size_t)dec * D, kvL, rows_p, e->row_stride, g.att + (size_t)dec * D, M - dec, max_chunks, nullptr, nullptr, nullptr, nullptr, 0, (sr.max_prefill_ctx + CHUNK - 1) / CHUNK}; HIP_TRY(launch_attention(aa, s)); }
+            }
         } else {
             { Prof p(e, K_ROPE, s); RopeArgs ra{g.qkv, g.qrot, kvL, g.dm.rows, e->row_stride, e->cos_t, e->sin_t, M}; HIP_TRY(launch_rope_kv(ra, s)); }
             { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot, kvL, g.dm.rows, e->row_stride, g.att, M, max_chunks, nullptr, nullptr, nullptr, nullptr, sr.n_prefill_rows > 0 ? sr.decode_rows : -1, (sr.max_prefill_ctx + CHUNK - 1) / CHUNK}; HIP_TRY(launch_attention(aa, s)); }
@@ -619,6 +630,7 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
             auto it = g.graphs.find(key);
             if (it == g.graphs.end()) {
                 hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+                const auto tc0 = std::chrono::steady_clock::now();
                 HIP_TRY(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
                 const int lrc = launch_step(e, g, sr);
                 const hipError_t ce = hipStreamEndCapture(g.stream, &graph);
@@ -632,6 +644,7 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
                     g.graphs.clear();
                 }
                 it = g.graphs.emplace(key, exec).first;
+                ++e->graph_captures; e->graph_capture_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
             }
             HIP_TRY(hipGraphLaunch(it->second, g.stream));
         } else {

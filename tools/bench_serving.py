@@ -35,4 +35,8 @@ print(json.dumps({"workload": f"C4: {n} requests (tests/golden/c4_requests.json 
                   "speech_tokens": total, "seconds": round(dt, 3), "speech_tokens_per_s": round(total / dt, 1), "steps": st.steps,
                   "decode_only_steps": st.decode_steps, "prefill_rows": st.prefill_rows, "audio_seconds_per_second": round(total / 25.0 / dt, 1),
                   "mean_ctx_decode": round(st.sum_ctx_decode / max(1, st.decode_rows), 1),
-                  "step_hbm_frac": round(st.algo_bytes_decode / max(1e-9, st.gpu_ms_decode * 1e-3) / 8e12, 4)}))
+                  "step_hbm_frac": round(st.algo_bytes_decode / max(1e-9, st.gpu_ms_decode * 1e-3) / 8e12, 4),
+                  "ms_per_decode_only_step": round(st.gpu_ms_decode / max(1, st.decode_steps), 3),
+                  "ms_per_mixed_step": round((st.gpu_ms_total - st.gpu_ms_decode) / max(1, st.steps - st.decode_steps), 3),
+                  "prefill_rows_per_mixed_step": round(st.prefill_rows / max(1, st.steps - st.decode_steps), 1)}))
+eng.close()
