@@ -388,7 +388,7 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
 template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
 __global__ __launch_bounds__(NW * 64) void gemm2_loop_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];      // [NW waves][MT][16 rows][KBS * 64 B] | NORM: float [NW][MT*16]
-    static_assert(NT <= KBS && (KBS == 8 || KBS == 2) && (NW == 4 || NW == 16) && (NW == 4 || (MT == 1 && NT == 1)), "gemm2_loop shapes");
+    static_assert(NT <= KBS && (KBS == 8 || KBS == 2) && (NW == 4 || NW == 16) && (NW == 4 || (MT == 1 && NT <= 2)), "gemm2_loop shapes");
     constexpr int LPR = KBS * 4, RPI = 64 / LPR, ABYTES = MT * KBS * 1024, TILES = MT * NT;
     constexpr int NTO = (EPI == EPI_SILU) ? NT / 2 : NT, PIECES = MT * NTO * 64, PIT = (PIECES + 255) / 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -467,12 +467,12 @@ __global__ __launch_bounds__(NW * 64) void gemm2_loop_kernel(GemmArgs a) {
         __syncthreads();
         auto part = [&](int w) { return reinterpret_cast<const float*>(lds2 + (size_t)w * ABYTES); };
         if constexpr (NW == 16) {
-            // 16 segments: one output per thread (256 of the 1024 threads), ((G0 + G1) + G2) + G3 with G = ((s0 + s1) + s2) + s3
-            if (tid < 256) {
-                const int r = (tid >> 6) & 3, l2 = tid & 63;
-                const int m = g * 16 + 4 * (l2 >> 4) + r, n = blockIdx.x * 16 + (l2 & 15);
+            // 16 segments: one output per thread (256 NT of the 1024 threads), ((G0 + G1) + G2) + G3 with G = ((s0 + s1) + s2) + s3
+            if (tid < 256 * NT) {
+                const int tl = tid >> 8, r = (tid >> 6) & 3, l2 = tid & 63;
+                const int m = g * 16 + 4 * (l2 >> 4) + r, n = (blockIdx.x * NT + tl) * 16 + (l2 & 15);
                 if (m < a.M && n < a.N) {
-                    const int o = r * 64 + l2;
+                    const int o = (tl * 4 + r) * 64 + l2;
                     float tot = 0.0f;
 #pragma unroll
                     for (int gsum = 0; gsum < 4; ++gsum) {
@@ -535,9 +535,9 @@ __global__ __launch_bounds__(NW * 64) void gemm2_loop_kernel(GemmArgs a) {
     // must be the oldest there: the hand-counted waits assume only asm loads behind them), at the start of every later one
     auto load_res = [&](int g) -> uint16_t {
         if constexpr (EPI == EPI_RESID) {
-            const int r = (tid >> 6) & 3, l2 = tid & 63;
-            const int m = g * 16 + 4 * (l2 >> 4) + r, n = blockIdx.x * 16 + (l2 & 15);
-            if (tid < 256 && m < a.M && n < a.N) return reinterpret_cast<const uint16_t*>(a.out)[(size_t)m * a.ldo + n];
+            const int tl = tid >> 8, r = (tid >> 6) & 3, l2 = tid & 63;
+            const int m = g * 16 + 4 * (l2 >> 4) + r, n = (blockIdx.x * NT + tl) * 16 + (l2 & 15);
+            if (tid < 256 * NT && m < a.M && n < a.N) return reinterpret_cast<const uint16_t*>(a.out)[(size_t)m * a.ldo + n];
         }
         return 0;
     };
@@ -846,7 +846,7 @@ static hipError_t launch_gemm2_loop_t(const GemmArgs* a, hipStream_t s) {
     const int mgroups = ((a->M + 15) / 16 + MT - 1) / MT;
     static int split_env = -1;
     if (split_env < 0) { const char* e = getenv(NW == 16 ? "T3_GEMM_LOOP16_SPLIT" : "T3_GEMM_LOOP_SPLIT"); split_env = e ? atoi(e) : 0; }
-    int gy = split_env > 0 ? split_env : (NW == 16 ? 4 : 2);
+    int gy = split_env > 0 ? split_env : (NW == 16 ? (NT == 2 ? 8 : 4) : 2);
     while (gy > 1 && mgroups / gy < (NW == 16 ? 1 : 2)) --gy;      // 4 waves: every workgroup walks at least two groups (16 waves: one is enough to win, measured)
     hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NW * 64), lds, s, *a);
     return hipGetLastError();
@@ -882,7 +882,9 @@ hipError_t prepare_gemm2() {
             if ((e = launch_gemm2_16(nullptr, epi, kbs, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<2, 1, EPI_BF16, 4, 8, true>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<2, 2, EPI_SILU, 4, 8, true>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<2, 4, EPI_SILU, 4, 8, true>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 8, false>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<1, 2, EPI_RESID, 16, 2, false>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 2, false>(nullptr, nullptr)) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -923,6 +925,12 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             // rows: 32 KiB of weights per workgroup do not pay for the walk) and keeps the one-workgroup-per-tile schedule.
             static int loop_min = -1;
             if (loop_min < 0) { const char* e = getenv("T3_GEMM_LOOP_MIN_ROWS"); loop_min = e ? atoi(e) : 81; }
+            // two gate/up pairs per workgroup (the weights of 4 packed tiles = 128 registers stationary, 256 in all, no spill): the
+            // rows pass through LDS once per 32 output columns instead of 16.  13.3 -> 10.5 us at 128 rows, 18.9 -> 16.6 at 256
+            // (T3_GEMM_LOOP_NT=2: one pair)
+            static int loop_nt = -1;
+            if (loop_nt < 0) { const char* e = getenv("T3_GEMM_LOOP_NT"); loop_nt = e ? atoi(e) : 4; }
+            if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU && loop_nt == 4) return launch_gemm2_loop_t<2, 4, EPI_SILU, 4, 8, true>(&a, s);
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_SILU) return launch_gemm2_loop_t<2, 2, EPI_SILU, 4, 8, true>(&a, s);
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_BF16 && getenv("T3_GEMM_LOOP_QKV")) return launch_gemm2_loop_t<2, 1, EPI_BF16, 4, 8, true>(&a, s);
         }
@@ -952,6 +960,15 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
         // at 96 rows, 11.9 -> 8.5 at 128, 21.9 -> 10.2 at 192, 19.4 -> 11.9 at 256; o 7.5 -> 6.0 at 256; at 64 rows the old form wins
         static int loop16_min = -1;
         if (loop16_min < 0) { const char* e = getenv("T3_GEMM_LOOP16_MIN_ROWS"); loop16_min = e ? atoi(e) : 81; }
+        {
+            static int nt16 = -1;
+            if (nt16 < 0) { const char* e = getenv("T3_GEMM_LOOP16_NT"); nt16 = e ? atoi(e) : 2; }
+            // two n-tiles per workgroup and 8 workgroups per n-tile pair: o only (6.0 -> 4.7 us at 256 rows, 4.3 -> 3.7 at 128).  The down form (8 k-blocks per wave) would need 170 registers at 16 waves per
+            // workgroup (128 available): hipcc spills, and a spilled destination of an in-flight asm load is a corrupted register
+            // later (tests/test_build.py keeps every asm-load kernel at zero spills)
+            if (loop16_min > 0 && a.M >= loop16_min && nt16 == 2 && a.N % 32 == 0 && a.K == D)
+                return launch_gemm2_loop_t<1, 2, EPI_RESID, 16, 2, false>(&a, s);
+        }
         if (loop16_min > 0 && a.M >= loop16_min)
             return a.K == D ? launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 2, false>(&a, s) : launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 8, false>(&a, s);
     }
