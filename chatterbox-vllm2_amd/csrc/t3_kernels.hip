@@ -966,7 +966,9 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             // two n-tiles per workgroup and 8 workgroups per n-tile pair: o only (6.0 -> 4.7 us at 256 rows, 4.3 -> 3.7 at 128).  The down form (8 k-blocks per wave) would need 170 registers at 16 waves per
             // workgroup (128 available): hipcc spills, and a spilled destination of an in-flight asm load is a corrupted register
             // later (tests/test_build.py keeps every asm-load kernel at zero spills)
-            if (loop16_min > 0 && a.M >= loop16_min && nt16 == 2 && a.N % 32 == 0 && a.K == D)
+            static int loop16_min_o = -1;
+            if (loop16_min_o < 0) { const char* e = getenv("T3_GEMM_LOOP16_MIN_ROWS_O"); loop16_min_o = e ? atoi(e) : (loop16_min > 0 ? 65 : 0); }     // o: 4.03 -> 3.74 us at 80 rows; at 64 rows the one-shot form wins (3.53 against 3.74)
+            if (loop16_min_o > 0 && a.M >= loop16_min_o && nt16 == 2 && a.N % 32 == 0 && a.K == D)
                 return launch_gemm2_loop_t<1, 2, EPI_RESID, 16, 2, false>(&a, s);
         }
         if (loop16_min > 0 && a.M >= loop16_min)

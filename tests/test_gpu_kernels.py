@@ -49,7 +49,7 @@ def test_gemm_16_segments_bit_exact(E, oracle, M, K, N, mt):
     assert_bit_equal(E.k_gemm(x, W, mt, nw=16), oracle.gemm(x, W, K // 16), f"16-segment gemm {M}x{K}x{N}")
 
 
-@pytest.mark.parametrize("M,K", [(64, 1024), (5, 4096), (40, 4096), (81, 4096), (96, 1024), (130, 1024), (129, 4096), (200, 1024), (256, 4096), (250, 4096)])  # 81+ rows: looped 16-wave schedule
+@pytest.mark.parametrize("M,K", [(64, 1024), (5, 4096), (40, 4096), (81, 4096), (70, 1024), (96, 1024), (130, 1024), (129, 4096), (200, 1024), (256, 4096), (250, 4096)])  # 81+ rows: looped 16-wave schedule
 def test_gemm_residual_epilogue_bit_exact(E, oracle, M, K):
     x = rand_bf16(M, K, seed=3); W = rand_bf16(1024, K, seed=4, scale=0.05); h = rand_bf16(M, 1024, seed=5, scale=2.0)
     y = oracle.gemm(x, W, K // 16).to(torch.bfloat16)
