@@ -31,3 +31,11 @@ st(a[:, 4] - a[:, 3], "barrier (slowest wave)")
 st(a[:, 5] - a[:, 4], "cross-chunk fold + store")
 st(a[:, 5] - a[:, 0], "workgroup lifetime")
 st(a[:, 5] - t0, "exit time since kernel start")
+# finish time by XCD (workgroup id % 8: the dispatcher deals workgroups round-robin over the 8 XCDs), by head and by row
+n = 32 * B
+wid = np.arange(n)                      # stamp slot = blockIdx.y * gridDim.x + blockIdx.x  (x = head, y = row)
+fin = a[:, 5] - t0
+x, y = wid % 16, wid // 16
+head = x
+for name, key in (("XCD (id % 8)", wid % 8), ("head", head), ("row % 8", y % 8)):
+    print(f"  finish time by {name}: " + "  ".join(f"{k}:{np.median(fin[key == k]):5.1f}/{fin[key == k].max():5.1f}" for k in sorted(set(key.tolist()))))
