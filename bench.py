@@ -256,6 +256,19 @@ def main():
                                "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "algo_bytes_per_launch": round(algo), "avg_launch_ms": round(ms, 5), "launches": kern[dom][1]}
             out["roofline"]["timing"] = "HIP events on the engine's stream around every launch of this kernel class in a pass of the same steps"
+            # the committed rocprofv3 --kernel-trace --stats average of the same kernel on the same workload, for comparison (an event
+            # pair around a launch costs ~2-3 us on top of the kernel: DESIGN.md section 6)
+            ks = os.path.join(ROOT, "profiles", "r02_d_kernel_stats_c3.csv")
+            rp_name = {"attention": "attention_kernel<4, true, true>"}.get(dom)
+            if rp_name and os.path.exists(ks) and args.batch == 32 and args.layers == 30:
+                import csv
+                for row in csv.DictReader(open(ks)):
+                    if rp_name in row["Name"]:
+                        rp_ms = float(row["AverageNs"]) * 1e-6
+                        out["roofline"]["rocprof_avg_launch_ms"] = round(rp_ms, 5)
+                        out["roofline"]["rocprof_frac"] = round(algo / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                        out["roofline"]["rocprof_source"] = "profiles/r02_d_kernel_stats_c3.csv (all 64-row launches of a 100-step run of this workload)"
+                        break
             out["kernel_ms_per_step_all_classes_evented"] = {k: round(tot[k] / pst.decode_steps, 4) for k in tot}   # eager + 2 events per kernel: over-reports
             out["profiled_ms_per_step"] = round(prof["dt"] / args.steps * 1e3, 4)
         if not args.no_cpu_baseline and world == 1:
