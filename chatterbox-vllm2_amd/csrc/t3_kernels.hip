@@ -379,7 +379,8 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// gemm2_loop_kernel: the NORM forms from ~100 rows on (decode steps of 64+ utterances, C4).  gemm2_kernel launches one
+// gemm2_loop_kernel: gate/up (4 waves, two gate/up pairs per workgroup), o and down (16 waves) from 65-81 rows on (decode steps of
+// 41+ utterances, C4; thresholds and measurements in launch_gemm).  gemm2_kernel launches one
 // workgroup per (n-group, m-group): at 256 rows that is 1024 single-occupancy workgroups in four rounds, each of which streams its
 // weight tiles again (268 MB of L2 -> CU traffic per layer) and pays a cold start.  Here a workgroup OWNS an n-group: its weight
 // tiles are loaded once and stay in registers, and it walks the m-groups, the next group's activation rows in flight (asm loads)
