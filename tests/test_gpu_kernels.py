@@ -147,6 +147,23 @@ def test_rope_paged_attention_bit_exact(E, oracle, lens):
     assert_bit_equal(got, want, f"attention lens={lens}")
 
 
+@pytest.mark.parametrize("layout", ["split_runs", "tiny_streams", "unaligned_chunks"])
+def test_rope_paged_attention_row_layouts(E, oracle, layout):
+    """Row lists the 16-rows-per-workgroup schedule and the 8-token V groups must survive: a stream continued later in the same
+    launch (two runs with other streams between them), many streams of 1-3 rows in one tile, runs that start off the 8-token grid."""
+    runs = {"split_runs": [(0, 0, 10), (1, 0, 5), (0, 10, 30), (2, 0, 1), (3, 0, 2), (1, 5, 21), (0, 30, 97)],
+            "tiny_streams": [(s, 0, 1 + s % 3) for s in range(40)],
+            "unaligned_chunks": [(0, 0, 3), (1, 0, 13), (0, 3, 70), (1, 13, 66), (2, 0, 129)]}[layout]
+    row_stream, row_pos = [], []
+    for s_, p0, p1 in runs:
+        row_stream += [s_] * (p1 - p0); row_pos += list(range(p0, p1))
+    n_streams = max(row_stream) + 1; max_pos = max(row_pos) + 2
+    qkv = rand_bf16(len(row_pos), 3072, seed=len(row_pos))
+    got = E.k_rope_attention(qkv, row_stream, row_pos, n_streams, max_pos)
+    want = _oracle_rope_attention(oracle, qkv, row_stream, row_pos, n_streams, max_pos)
+    assert_bit_equal(got, want, f"attention layout={layout}")
+
+
 def test_attention_peaky_scores(E, oracle):
     """Large-magnitude q/k: softmax saturates, exp underflows to 0 for most keys (rule-26 style forcing input)."""
     L = 150
