@@ -142,6 +142,78 @@ extern "C" int t3k_rope_attention(const void* qkv, const int32_t* row_stream, co
     return T3_OK;
 }
 
+/* The FUSED decode attention exactly as a decode step launches it (attention_kernel<waves, nt, FUSE = true>: RoPE of q / k, paged
+ * write of the newest K / V, attention over the paged context), `steps` consecutive launches of `rows` rows:
+ *   - stream r (= row r) holds ctx[r] - 1 context tokens whose pre-RoPE qkv rows are ctx_qkv[content r % n_content][0 .. ctx[r] - 2]
+ *     (written into a scrambled paged pool by rope_kv_kernel, the prefill path);
+ *   - launch s processes, for every row r, the pre-RoPE row new_qkv[s][r] at position ctx[r] - 1 + s: launch s >= 1 therefore
+ *     reads the K / V that launch s - 1 wrote through the fused path.
+ * out [steps][rows][1024]; kv_new (nullable) [steps][rows][2][1024]: K (rotated) and V of the positions the launches wrote, read
+ * back from the pool. */
+extern "C" int t3k_decode_attention(const void* ctx_qkv, int32_t n_content, int32_t content_rows, const void* new_qkv, const int32_t* ctx,
+                                    int32_t rows, int32_t steps, int32_t max_pos, int32_t waves, void* out, void* kv_new) {
+    if (!ctx_qkv || !new_qkv || !ctx || !out || rows <= 0 || steps <= 0 || n_content <= 0 || content_rows <= 0 || max_pos <= 0 ||
+        (waves != 0 && waves != 4 && waves != 8)) return T3_E_INVALID;
+    for (int r = 0; r < rows; ++r)
+        if (ctx[r] < 1 || ctx[r] - 1 > content_rows || ctx[r] - 1 + steps > max_pos) return T3_E_INVALID;
+    if (!have_device()) return T3_E_DEVICE;
+    const int max_blocks = (max_pos + KV_BLOCK - 1) / KV_BLOCK, nb = rows * max_blocks;
+    std::vector<int> table(nb);
+    for (int i = 0; i < nb; ++i) table[i] = (int)(((long)i * 7919 + 13) % nb);
+    {
+        std::vector<char> seen(nb, 0); bool ok = true;
+        for (int i = 0; i < nb; ++i) { if (seen[table[i]]) ok = false; seen[table[i]] = 1; }
+        if (!ok) for (int i = 0; i < nb; ++i) table[i] = nb - 1 - i;
+    }
+    std::vector<float> c((size_t)max_pos * 32), s((size_t)max_pos * 32);
+    rope_tables(max_pos, c.data(), s.data());
+    const int stride = row_stride_words(max_blocks);
+    DevBuf dctx, dnew, dc, ds, dq, dkv, dout, dkvn, drec_fill, drec;
+    K_TRY(dctx.from(ctx_qkv, (size_t)n_content * content_rows * QKV * 2)); K_TRY(dnew.from(new_qkv, (size_t)steps * rows * QKV * 2));
+    K_TRY(dc.from(c.data(), c.size() * 4)); K_TRY(ds.from(s.data(), s.size() * 4));
+    K_TRY(dq.alloc((size_t)content_rows * D * 2));                     // rotated q of the fill rows: not used
+    K_TRY(dkv.alloc((size_t)nb * KV_BLOCK_ELEMS * 2, true)); K_TRY(dout.alloc((size_t)steps * rows * D * 2, true));
+    K_TRY(dkvn.alloc((size_t)steps * rows * 2 * D * 2, true));
+    // ---- context fill: one rope_kv launch per stream over its content's rows (positions 0 .. ctx[r] - 2)
+    std::vector<int> recs((size_t)content_rows * stride);
+    K_TRY(drec_fill.alloc(recs.size() * 4));
+    for (int r = 0; r < rows; ++r) {
+        const int n = ctx[r] - 1;
+        if (n <= 0) continue;
+        for (int p = 0; p < n; ++p) {
+            int* rec = recs.data() + (size_t)p * stride;
+            memset(rec, 0, (size_t)stride * 4);
+            rec[0] = r; rec[1] = p;
+            for (int b = 0; b < max_blocks; ++b) rec[ROW_HDR + b] = table[(size_t)r * max_blocks + b];
+        }
+        K_TRY(hipMemcpy(drec_fill.p, recs.data(), (size_t)n * stride * 4, hipMemcpyHostToDevice));
+        RopeArgs ra{dctx.as<uint16_t>() + (size_t)(r % n_content) * content_rows * QKV, dq.as<uint16_t>(), dkv.as<uint16_t>(), drec_fill.as<int>(), stride,
+                    dc.as<float>(), ds.as<float>(), n};
+        K_TRY(launch_rope_kv(ra, nullptr));
+        K_TRY(hipDeviceSynchronize());                                 // the record buffer is reused by the next stream
+    }
+    // ---- the decode launches
+    std::vector<int> drecs((size_t)rows * stride, 0);
+    K_TRY(drec.alloc(drecs.size() * 4));
+    for (int st = 0; st < steps; ++st) {
+        for (int r = 0; r < rows; ++r) {
+            int* rec = drecs.data() + (size_t)r * stride;
+            rec[0] = r; rec[1] = ctx[r] - 1 + st;
+            for (int b = 0; b < max_blocks; ++b) rec[ROW_HDR + b] = table[(size_t)r * max_blocks + b];
+        }
+        K_TRY(hipMemcpy(drec.p, drecs.data(), drecs.size() * 4, hipMemcpyHostToDevice));
+        AttnArgs aa{nullptr, dkv.as<uint16_t>(), drec.as<int>(), stride, dout.as<uint16_t>() + (size_t)st * rows * D, rows, (max_pos + CHUNK - 1) / CHUNK,
+                    dnew.as<uint16_t>() + (size_t)st * rows * QKV, dkv.as<uint16_t>(), dc.as<float>(), ds.as<float>()};
+        aa.force_waves = waves;
+        K_TRY(launch_attention(aa, nullptr));
+        K_TRY(launch_kv_gather(dkv.as<uint16_t>(), drec.as<int>(), stride, rows, dkvn.as<uint16_t>() + (size_t)st * rows * 2 * D, nullptr));
+        K_TRY(hipDeviceSynchronize());
+    }
+    K_TRY(hipMemcpy(out, dout.p, (size_t)steps * rows * D * 2, hipMemcpyDeviceToHost));
+    if (kv_new) K_TRY(hipMemcpy(kv_new, dkvn.p, (size_t)steps * rows * 2 * D * 2, hipMemcpyDeviceToHost));
+    return T3_OK;
+}
+
 extern "C" int t3k_sample(const void* logits2, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg, uint32_t step,
                           int32_t* token_out, float* logits_out) {
     if (!logits2 || !counts || !sp || !token_out || ldl < V) return T3_E_INVALID;

@@ -92,8 +92,11 @@ struct AttnArgs {
     // unfused form: rows [tile_from, rows) are prefill rows and take the 16-rows-per-workgroup schedule (-1: none); tile_chunks =
     // ceil(longest context among them / 64) sizes its LDS (0: max_chunks)
     int tile_from = -1, tile_chunks = 0;
+    int force_waves = 0;       // 4 / 8: waves per (row, head) workgroup of the per-row kernel (0: by row count; parity tests check both)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+// parity hook: K (as stored, i.e. rotated) and V of every row's (stream, position) read back from the paged pool -> out [rows][2][1024]
+hipError_t launch_kv_gather(const uint16_t* kv_layer, const int* rowrec, int row_stride, int rows, uint16_t* out, hipStream_t s);
 
 struct SampleArgs {
     const uint16_t* logits;    // [2*n][ldl] bf16: row 2i cond, 2i+1 uncond

@@ -812,16 +812,21 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// hipFuncSetAttribute applies to the CURRENT device: every "already raised" flag below is kept per device, so a process that
+// drives engines on several GPUs (LLM(device_id=...)) raises the limits on each of them
+constexpr int MAX_DEVICES = 64;
+static inline int cur_device() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < MAX_DEVICES ? d : 0; }
+
 // gemm2_kernel launcher; a == nullptr: only raise the kernel's dynamic-LDS limit (prepare_kernels, before any stream capture)
 template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
 static hipError_t launch_gemm2_t(const GemmArgs* a, hipStream_t s) {
     constexpr size_t lds = (size_t)NW * MT * KBS * 1024 + (NORM ? (size_t)NW * MT * 16 * sizeof(float) : 0);
     auto kern = gemm2_kernel<MT, NT, EPI, NW, KBS, NORM>;
-    static bool raised = false;
-    if (!raised && lds > 64 * 1024) {
+    static bool raised[MAX_DEVICES] = {};
+    if (lds > 64 * 1024 && !raised[cur_device()]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        raised = true;
+        raised[cur_device()] = true;
     }
     if (!a) return hipSuccess;
     const int ntiles = a->packed_tiles > 0 ? a->packed_tiles / (EPI == EPI_SILU ? 2 : 1) : (a->N + 15) / 16;
@@ -835,11 +840,11 @@ template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
 static hipError_t launch_gemm2_loop_t(const GemmArgs* a, hipStream_t s) {
     constexpr size_t lds = (size_t)NW * MT * KBS * 1024 + (NORM ? (size_t)NW * MT * 16 * sizeof(float) : 0);
     auto kern = gemm2_loop_kernel<MT, NT, EPI, NW, KBS, NORM>;
-    static bool raised = false;
-    if (!raised && lds > 64 * 1024) {
+    static bool raised[MAX_DEVICES] = {};
+    if (lds > 64 * 1024 && !raised[cur_device()]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        raised = true;
+        raised[cur_device()] = true;
     }
     if (!a) return hipSuccess;
     const int ntiles = (a->N + 15) / 16;
@@ -1164,6 +1169,27 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(RopeArgs a) {
 hipError_t launch_rope_kv(const RopeArgs& a, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(rope_kv_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+// parity hook (t3k_decode_attention): the K / V of a row's (stream, position) as the pool holds them, one wave per row, lane = (head, part)
+__global__ __launch_bounds__(256) void kv_gather_kernel(const uint16_t* kv_layer, const int* rowrec, int row_stride, int rows, uint16_t* out) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int* rec = rowrec + (size_t)row * row_stride;
+    const int pos = rec[1], blk = rec[ROW_HDR + pos / KV_BLOCK], tok = pos % KV_BLOCK;
+    const int h = lane >> 2, part = lane & 3;
+    const uint16_t* kb = kv_layer + kv_head_base(blk, 0, h);
+    const uint16_t* vb = kv_layer + kv_head_base(blk, 1, h);
+    uint16_t* ko = out + (size_t)row * 2 * D + h * HD;
+    uint16_t* vo = ko + D;
+    *reinterpret_cast<uint4*>(ko + part * 8) = *reinterpret_cast<const uint4*>(kb + k_slot(tok, 0, part));
+    *reinterpret_cast<uint4*>(ko + 32 + part * 8) = *reinterpret_cast<const uint4*>(kb + k_slot(tok, 1, part));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) vo[part * 16 + e] = vb[v_elem(tok, part * 16 + e)];
+}
+hipError_t launch_kv_gather(const uint16_t* kv_layer, const int* rowrec, int row_stride, int rows, uint16_t* out, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kv_gather_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, kv_layer, rowrec, row_stride, rows, out);
     return hipGetLastError();
 }
 
@@ -1553,15 +1579,21 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
     static int nw_env = -1, nt = 0, tile_on = 1;
     if (nw_env < 0) { const char* e = getenv("T3_ATTN_WAVES"); nw_env = e ? atoi(e) : 0; const char* t = getenv("T3_ATTN_NT"); nt = t ? atoi(t) : 1; const char* p = getenv("T3_ATTN_TILE"); tile_on = p ? atoi(p) : 1; }
-    if (!a.qkv && tile_on && a.tile_from >= 0 && a.tile_from < a.rows) {
-        // unfused form: rows [tile_from, rows) are prefill rows (runs of consecutive positions of a stream): 16 rows per workgroup
-        const int cap = a.tile_chunks > 0 ? min(a.tile_chunks, a.max_chunks) : a.max_chunks;
-        const size_t lds_t = ((size_t)cap * 16 * (TILE_OS + 2)) * sizeof(float) + (size_t)4 * 16 * TILE_PS * 2;
-        static size_t raised = 64 * 1024;
-        if (lds_t > raised) {
+    // unfused form: rows [tile_from, rows) are prefill rows (runs of consecutive positions of a stream): 16 rows per workgroup.
+    // The tile kernel keeps every chunk's partials of its 16 rows in LDS (4.5 KiB per chunk): beyond 35 chunks (a prefill context
+    // over 2 240 tokens) that no longer fits the 160 KiB of a gfx950 CU, and such rows take the per-row kernel below (34 KiB at
+    // max_model_len 8192), which computes the same numbers.
+    const int cap = a.tile_chunks > 0 ? min(a.tile_chunks, a.max_chunks) : a.max_chunks;
+    const size_t lds_t = ((size_t)cap * 16 * (TILE_OS + 2)) * sizeof(float) + (size_t)4 * 16 * TILE_PS * 2;
+    constexpr size_t LDS_PER_CU = 160 * 1024;
+    if (!a.qkv && tile_on && a.tile_from >= 0 && a.tile_from < a.rows && lds_t <= LDS_PER_CU) {
+        static size_t raised[MAX_DEVICES] = {};
+        size_t& have = raised[cur_device()];
+        if (have < 64 * 1024) have = 64 * 1024;
+        if (lds_t > have) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
             if (e != hipSuccess) return e;
-            raised = lds_t;
+            have = lds_t;
         }
         hipLaunchKernelGGL(attention_tile_kernel, dim3(H, (a.rows - a.tile_from + 15) / 16), dim3(256), lds_t, s, a, a.tile_from, cap);
         hipError_t e = hipGetLastError();
@@ -1571,7 +1603,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     }
     // 4 waves per (row, head) fill the chip from 16 rows on (16 heads x 16 rows x 4 waves = 4 waves per CU); below that the
     // launch is latency-bound and 8 waves halve the number of sequential 64-token chunks per wave (B = 1: 2 rows -> 32 workgroups)
-    const int nw = nw_env == 4 || nw_env == 8 ? nw_env : (a.rows <= 8 ? 8 : 4);
+    const int nw = a.force_waves == 4 || a.force_waves == 8 ? a.force_waves : nw_env == 4 || nw_env == 8 ? nw_env : (a.rows <= 8 ? 8 : 4);
     const dim3 grid(H, a.rows);
     const bool fuse = a.qkv != nullptr;
     const size_t lds = ((size_t)a.max_chunks * 66 + (size_t)(nw == 8 ? 8 : 4) * (96 + (fuse ? 12 * 64 : 0))) * sizeof(float);
@@ -1887,12 +1919,12 @@ __global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
     }
 }
 hipError_t prepare_kernels() {
-    static bool done = false;
-    if (done) return hipSuccess;
+    static bool done[MAX_DEVICES] = {};
+    if (done[cur_device()]) return hipSuccess;
     const size_t lds = (size_t)(SLOTS + 8 + 256) * sizeof(unsigned long long);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) e = prepare_gemm2();
-    if (e == hipSuccess) done = true;
+    if (e == hipSuccess) done[cur_device()] = true;
     return e;
 }
 hipError_t launch_sampler(const SampleArgs& a, hipStream_t s) {

@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "t3_create", "t3_destroy", "t3_last_error", "t3_load_tensor", "t3_finalize_weights", "t3_add_request",
     "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_release_request", "t3_abort_request", "t3_handoff_tokens", "t3k_handoff",
     "t3_clean_tokens", "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_set_profile_kernel", "t3_kernel_ms",
-    "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_sample", "t3k_expf",
+    "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_decode_attention", "t3k_sample", "t3k_expf",
     "t3_cond_create", "t3_cond_destroy", "t3_cond_last_error", "t3_cond_load_tensor", "t3_cond_encode", "t3_cond_emotion_row",
     "t3k_ce_layernorm", "t3k_ce_linear", "t3k_ce_attention", "t3k_set_prefill_rows", "t3k_set_prefill_wide_rows",
 ]
@@ -118,6 +118,7 @@ def load_library():
     L.t3k_gemm_resid.argtypes = [vp, vp, i32, i32, i32, vp]
     L.t3k_silu_mul_gemm.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.t3k_rope_attention.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.t3k_decode_attention.argtypes = [vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp]
     L.t3k_sample.argtypes = [vp, i32, vp, ct.POINTER(T3Sampling), ct.c_float, ct.c_uint32, vp, vp]
     L.t3k_expf.argtypes = [vp, vp, i32]
     L.t3_cond_create.argtypes = [i32, ct.POINTER(vp)]
@@ -348,6 +349,20 @@ def k_rope_attention(qkv: torch.Tensor, row_stream, row_pos, n_streams: int, max
     _chk_k(load_library().t3k_rope_attention(qkv.data_ptr(), rs.ctypes.data, rp.ctypes.data, qkv.shape[0], n_streams, max_pos,
                                              out.data_ptr()), "t3k_rope_attention")
     return out
+
+
+def k_decode_attention(ctx_qkv: torch.Tensor, new_qkv: torch.Tensor, ctx, max_pos: int, waves: int = 0):
+    """The fused decode attention kernel (RoPE + KV write + paged attention in one launch), `steps` consecutive launches.
+    ctx_qkv [n_content, content_rows, 3072] bf16 pre-RoPE context rows (stream r takes content r % n_content, positions 0 .. ctx[r] - 2),
+    new_qkv [steps, rows, 3072], ctx int list [rows] -> (out [steps, rows, 1024] bf16, kv_new [steps, rows, 2, 1024] bf16)."""
+    ctx_qkv, new_qkv = _bf(ctx_qkv), _bf(new_qkv)
+    cx = np.ascontiguousarray(np.asarray(ctx, dtype=np.int32))
+    steps, rows = new_qkv.shape[0], new_qkv.shape[1]
+    assert ctx_qkv.dim() == 3 and ctx_qkv.shape[2] == 3072 and new_qkv.shape[2] == 3072 and len(cx) == rows
+    out = torch.empty(steps, rows, C.HIDDEN, dtype=torch.bfloat16); kvn = torch.empty(steps, rows, 2, C.HIDDEN, dtype=torch.bfloat16)
+    _chk_k(load_library().t3k_decode_attention(ctx_qkv.data_ptr(), ctx_qkv.shape[0], ctx_qkv.shape[1], new_qkv.data_ptr(), cx.ctypes.data,
+                                               rows, steps, int(max_pos), int(waves), out.data_ptr(), kvn.data_ptr()), "t3k_decode_attention")
+    return out, kvn
 
 
 def k_sample(logits2: torch.Tensor, counts: torch.Tensor, sp: T3Sampling, cfg: float, step: int):

@@ -215,6 +215,15 @@ int t3k_silu_mul_gemm(const void* h_bf16 /*[M][1024]*/, const void* ln_w_bf16, c
  * cover a prefix of positions.  out [rows][1024] bf16.                                        */
 int t3k_rope_attention(const void* qkv_bf16, const int32_t* row_stream, const int32_t* row_pos, int32_t rows,
                        int32_t n_streams, int32_t max_pos, void* out_bf16);
+/* The FUSED decode attention as a decode step launches it (RoPE of q / k + paged write of the newest K / V + attention over the
+ * paged context in ONE kernel; what vLLM's rotary_embedding + reshape_and_cache + paged attention do per layer behind
+ * t3.py:703-708), `steps` consecutive launches of `rows` rows over a scrambled scratch pool:
+ *   stream r (= row r) holds ctx[r] - 1 context tokens, pre-RoPE qkv rows ctx_qkv[r % n_content][0 .. ctx[r] - 2] ([n_content][content_rows][3072]
+ *   bf16), written through the prefill path; launch s takes new_qkv[s][r] ([steps][rows][3072]) at position ctx[r] - 1 + s, so launch
+ *   s >= 1 reads what launch s - 1 wrote.  waves: 0 = as the engine picks (8 up to 8 rows, else 4), or 4 / 8.
+ * out bf16 [steps][rows][1024]; kv_new (nullable) bf16 [steps][rows][2][1024] = K (rotated) and V of the written positions, read back. */
+int t3k_decode_attention(const void* ctx_qkv_bf16, int32_t n_content, int32_t content_rows, const void* new_qkv_bf16, const int32_t* ctx,
+                         int32_t rows, int32_t steps, int32_t max_pos, int32_t waves, void* out_bf16, void* kv_new_bf16);
 /* CFG + sampler: logits bf16 [2][ldl] (cond row, uncond row), counts uint16 [8194] (updated). */
 int t3k_sample(const void* logits2_bf16, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg,
                uint32_t step, int32_t* token_out, float* logits_out_8194 /*nullable*/);

@@ -17,6 +17,7 @@ What comes from where:
                           tokenizer JSON files via the `tokenizers` library.
   G9  c4_requests.json -- token ids of the sentences of the reference's docs/benchmark-text-*.txt (C4 request stream)
   G6b streams30.npz    -- 30-layer oracle streams for C3 uids 0 / 17 and six C4 requests (multilingual vocabulary)
+  G6c streams30_full.npz -- FULL-LENGTH 30-layer oracle streams: C3 uids 0 / 17 (884 / 859 tokens), C2 (292), two C4 requests
 No reference source text is stored: only inputs and numeric outputs.
 """
 import json
@@ -252,6 +253,48 @@ def g6b_streams_30_layers_multilingual():
     print("G6b streams30:", {k: v.shape for k, v in out.items()})
 
 
+C4_FULL_LENGTH_REQUESTS = (431, 464)                 # fr (T = 268, 317 tokens), zh (T = 57, 767 tokens)
+
+
+def g6c_full_length_streams():
+    """FULL-LENGTH 30-layer oracle streams (ids only): C3 utterances 0 (en, 884 tokens) and 17 (es, 859 tokens) to max_model_len 1000,
+    C2's 292 tokens (English vocabulary, max_model_len 400) and two C4 requests to their max_tokens -- so that the device path is
+    compared with the oracle to the END of the headline configurations (contexts up to 1000, every 256-token KV block boundary, the
+    4-wave attention at >= 3 chunks per wave), not only over their first 24-32 tokens.  ~1 h of CPU on 8 cores; saved stream by stream."""
+    from oracle import oracle as O
+    from chatterbox_vllm2_amd.prompt import assemble_prompt_ids
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb, synthetic_tensors
+    tok = json.load(open(os.path.join(HERE, "tokenizer.json")))
+    c4 = json.load(open(os.path.join(HERE, "c4_requests.json")))
+    cond = synthetic_cond_emb(1)
+    path = os.path.join(HERE, "streams30_full.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, ignore_eos=True)
+
+    def run(m, key, prompt, sp, mml):
+        if key in out:
+            return
+        import time
+        t0 = time.time()
+        ids, _ = m.generate(prompt, cond, sp, max_model_len=mml)
+        out[key] = np.array(ids, np.int16 if max(ids) < 32768 else np.int32)
+        np.savez_compressed(path, **out)
+        print(f"  {key}: {len(ids)} tokens, T = {len(prompt)}, {time.time() - t0:.0f} s", ids[:6], flush=True)
+
+    m = O.OracleModel(30, 704, max_pos=400).load(synthetic_tensors(30, 704, 1234))
+    run(m, "c2_en_sampled_ids", assemble_prompt_ids(tok["en_english_ids"]), O.make_sampling(uid=0, max_tokens=400 - 108, **kw), 400)
+    m.close()
+    m = O.OracleModel(30, 2454, max_pos=1000).load(synthetic_tensors(30, 2454, 1234))
+    for i in C4_FULL_LENGTH_REQUESTS:
+        r = c4["requests"][i]
+        run(m, f"c4_req{i}_ids", assemble_prompt_ids(r["text_ids"]), O.make_sampling(uid=i, max_tokens=r["max_tokens"], **kw), 1000)
+    for uid, key in ((17, "es_mtl_ids"), (0, "en_mtl_ids")):
+        p = assemble_prompt_ids(tok[key])
+        run(m, f"c3_uid{uid}_ids", p, O.make_sampling(uid=uid, max_tokens=1000 - len(p), **kw), 1000)
+    m.close()
+    print("G6c full-length streams:", {k: v.shape for k, v in out.items()})
+
+
 def g8_postfilter():
     """Decisions of the reference's AlignmentStreamAnalyzer (imported; run on CPU) driven by the loop of tts.py:329-350."""
     import importlib
@@ -299,3 +342,4 @@ if __name__ == "__main__":
     if "g8" in which: g8_postfilter()
     if "g9" in which: g9_c4_requests()
     if "g6b" in which: g6b_streams_30_layers_multilingual()
+    if "g6c" in which: g6c_full_length_streams()          # not in the default list: about an hour of CPU

@@ -173,6 +173,82 @@ def test_attention_peaky_scores(E, oracle):
     assert_bit_equal(got, want, "attention peaky")
 
 
+def _oracle_decode_attention(oracle, ctx_qkv, new_qkv, ctx, max_pos):
+    """oracle.rope + oracle.attn_row over the same inputs as E.k_decode_attention: per stream the rotated K / V of its content's
+    context rows, then `steps` newest positions appended one by one."""
+    cos_t, sin_t = oracle.rope_table(max_pos)
+    steps, rows = new_qkv.shape[0], new_qkv.shape[1]
+    n_content, content_rows = ctx_qkv.shape[0], ctx_qkv.shape[1]
+    pos_all = torch.arange(content_rows, dtype=torch.int32)
+    Kc = [oracle.rope(ctx_qkv[c, :, 1024:2048], pos_all, cos_t, sin_t) for c in range(n_content)]      # rotated once per content
+    Vc = [ctx_qkv[c, :, 2048:].contiguous() for c in range(n_content)]
+    out = torch.empty(steps, rows, 1024, dtype=torch.bfloat16); kvn = torch.empty(steps, rows, 2, 1024, dtype=torch.bfloat16)
+    for r in range(rows):
+        n = int(ctx[r]) - 1
+        K = torch.cat([Kc[r % n_content][:n], torch.zeros(steps, 1024, dtype=torch.bfloat16)])
+        V = torch.cat([Vc[r % n_content][:n], torch.zeros(steps, 1024, dtype=torch.bfloat16)])
+        for s in range(steps):
+            p = torch.tensor([n + s], dtype=torch.int32)
+            q = oracle.rope(new_qkv[s, r:r + 1, :1024], p, cos_t, sin_t)[0]
+            K[n + s] = oracle.rope(new_qkv[s, r:r + 1, 1024:2048], p, cos_t, sin_t)[0]
+            V[n + s] = new_qkv[s, r, 2048:]
+            kvn[s, r, 0] = K[n + s]; kvn[s, r, 1] = V[n + s]
+            L = n + s + 1
+            for h in range(16):
+                sl = slice(h * 64, (h + 1) * 64)
+                out[s, r, sl] = oracle.attn_row(q[sl], K[:L, sl], V[:L, sl])
+    return out, kvn
+
+
+DECODE_CTX = [63, 64, 65, 255, 256, 257, 511, 512, 513, 559, 767, 768, 999]
+
+
+@pytest.mark.parametrize("rows,waves", [(2, 8), (2, 4), (9, 4), (9, 8), (64, 4), (64, 8)])
+def test_fused_decode_attention_bit_exact(E, oracle, rows, waves):
+    """THE headline kernel (attention_kernel<waves, nt, FUSE>: 51 % of the decode step's GPU time) against oracle.rope + oracle.attn_row
+    at the contexts the bench times it at and beyond: every KV-block boundary (256 / 512 / 768), chunk boundaries (63 / 64 / 65),
+    >= 3 chunk iterations per wave (4 waves from ctx 513), the longest context of max_model_len 1000; the rows of a launch carry
+    DIFFERENT contexts (row r of launch j takes DECODE_CTX[(r + j) % 13]), two consecutive launches per case (the second reads the
+    K / V the first wrote through the fused path), and the written K / V themselves are read back and compared."""
+    max_pos = 1001
+    ctx_qkv = rand_bf16(min(rows, 3), 998, 3072, seed=rows)
+    launches = len(DECODE_CTX) if rows <= 9 else 2
+    for j in range(launches):
+        ctx = [DECODE_CTX[(r + j) % len(DECODE_CTX)] for r in range(rows)]
+        new_qkv = rand_bf16(2, rows, 3072, seed=1000 * rows + j)
+        got, kv_got = E.k_decode_attention(ctx_qkv, new_qkv, ctx, max_pos, waves)
+        want, kv_want = _oracle_decode_attention(oracle, ctx_qkv, new_qkv, ctx, max_pos)
+        assert_bit_equal(kv_got, kv_want, f"newest K / V written by the fused kernel, rows={rows} waves={waves} launch {j}")
+        assert_bit_equal(got, want, f"fused decode attention rows={rows} waves={waves} launch {j}")
+
+
+def test_fused_decode_attention_256_rows(E, oracle):
+    """A 128-utterance decode step (C4): 256 rows in one launch, contexts spread over the 13 boundary cases, as the engine picks the waves."""
+    rows, max_pos = 256, 1001
+    ctx_qkv = rand_bf16(2, 998, 3072, seed=77)
+    ctx = [DECODE_CTX[(5 * r) % len(DECODE_CTX)] for r in range(rows)]
+    new_qkv = rand_bf16(1, rows, 3072, seed=78)
+    got, kv_got = E.k_decode_attention(ctx_qkv, new_qkv, ctx, max_pos, 0)
+    want, kv_want = _oracle_decode_attention(oracle, ctx_qkv, new_qkv, ctx, max_pos)
+    assert_bit_equal(kv_got, kv_want, "newest K / V, 256 rows")
+    assert_bit_equal(got, want, "fused decode attention, 256 rows")
+
+
+def test_prefill_attention_beyond_tile_lds(E, oracle):
+    """A prompt whose context no longer fits the 16-row tile kernel's LDS (> 35 chunks = 2 240 tokens: 160 KiB per CU) must still
+    prefill: launch_attention sends such rows to the per-row kernel.  One stream of 2 300 positions in one launch (every row's KV is
+    written, then attention over all of them); a sample of rows is compared with the oracle, the last ones included."""
+    L = 2300
+    qkv = rand_bf16(L, 3072, seed=23)
+    got = E.k_rope_attention(qkv, [0] * L, list(range(L)), 1, L + 1)
+    cos_t, sin_t = oracle.rope_table(L + 1)
+    pos = torch.arange(L, dtype=torch.int32)
+    q = oracle.rope(qkv[:, :1024], pos, cos_t, sin_t); k = oracle.rope(qkv[:, 1024:2048], pos, cos_t, sin_t); v = qkv[:, 2048:].contiguous()
+    for r in [0, 63, 64, 1000, 2175, 2176, 2239, 2240, 2241, 2298, 2299]:
+        want = torch.cat([oracle.attn_row(q[r, h * 64:(h + 1) * 64], k[:r + 1, h * 64:(h + 1) * 64], v[:r + 1, h * 64:(h + 1) * 64]) for h in range(16)])
+        assert_bit_equal(got[r], want, f"row {r} of a {L}-token prefill")
+
+
 SAMPLING_CASES = [
     dict(temperature=0.0),
     dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0),
