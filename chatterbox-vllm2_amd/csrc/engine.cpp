@@ -55,6 +55,7 @@ struct Request {
     int n_sched = 0, last_idx = -1;
     bool zombie = false;
     int32_t* d_out = nullptr;         // finished: the utterance's speech-space ids on the device (f4 hand-off), from the engine's buffer pool
+    double t_add = 0, t_admit = 0, t_first = 0, t_finish = 0;     // seconds since the engine was created (t3_get_timing)
 };
 
 enum KClass { K_QKV, K_O, K_GU, K_DOWN, K_HEAD, K_ATTN, K_ROPE, K_EMBED, K_SAMPLE, K_COUNT };
@@ -128,7 +129,16 @@ struct T3Engine {
     T3Sampling* d_sp = nullptr;
     float* d_dbg = nullptr;
     int32_t* d_hist = nullptr;         // [max_seqs][max_model_len]: the sampler appends every token it draws (slot-indexed)
+    // f4 hand-off: finished utterances keep their ids in a device buffer of their own (the slot's history is reused by the next
+    // occupant) ONLY while the caller has asked for it (t3_reserve_handoff); the pool is grown there, outside the step loop
+    bool keep_device_ids = false;
     std::vector<int32_t*> out_pool;    // free per-utterance device id buffers (max_model_len ints each)
+    std::vector<void*> out_slabs;      // the allocations the pool was carved from
+    HandoffItem* d_handoff_items = nullptr; int handoff_items_cap = 0;      // persistent argument buffer of t3_handoff_tokens
+    hipEvent_t ev_handoff = nullptr;
+    std::deque<int64_t> finished_q;    // ids finished since the last t3_pop_finished (T3StepResult carries only the first 64 of a step)
+    uint16_t* d_dbg_emb = nullptr;     // debug_logits: the embedded input rows of the most recent step (t3_debug_embeddings)
+    std::vector<int> dbg_emb_rec;      // their (stream, position) pairs
 
     // scheduler
     std::unordered_map<int64_t, Request> reqs;
@@ -146,6 +156,8 @@ struct T3Engine {
     double k_ms[K_COUNT] = {0};
     int64_t k_n[K_COUNT] = {0};
 
+    std::chrono::steady_clock::time_point t_created = std::chrono::steady_clock::now();
+    double now_s() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_created).count(); }
     int fail(int code, const std::string& m) { err = m; return code; }
     // algorithmic weight bytes streamed once per step (SURVEY.md 8(d) "W"): bf16 backbone incl. norms + speech head
     double weight_bytes_for_step() const {
@@ -219,8 +231,9 @@ extern "C" int t3_destroy(T3Handle e) {
         if (g.stream) (void)hipStreamDestroy(g.stream);
     }
     free_dev(e->d_cond); free_dev(e->d_counts); free_dev(e->d_sp); free_dev(e->d_dbg); free_dev(e->d_hist);
-    for (auto* b : e->out_pool) free_dev(b);
-    for (auto& kv : e->reqs) free_dev(kv.second.d_out);
+    for (void* b : e->out_slabs) free_dev(b);      // every hand-off buffer (pooled or held by a request) lives in one of these
+    free_dev(e->d_handoff_items); free_dev(e->d_dbg_emb);
+    if (e->ev_handoff) (void)hipEventDestroy(e->ev_handoff);
     if (e->ev_admit) (void)hipEventDestroy(e->ev_admit);
     for (int k = 0; k < K_COUNT; ++k) for (auto& p : e->pev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -399,6 +412,8 @@ extern "C" int t3_finalize_weights(T3Handle e) {
     if ((rc = dalloc(e, &e->d_counts, S * VPAD, true))) return rc;
     if ((rc = dalloc(e, &e->d_sp, S, true))) return rc;
     if (e->cfg.debug_logits && (rc = dalloc(e, &e->d_dbg, S * V, true))) return rc;
+    if (e->cfg.debug_logits && e->n_groups == 1 && (rc = dalloc(e, &e->d_dbg_emb, (size_t)e->groups[0].rcap * D, true))) return rc;
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_handoff, hipEventDisableTiming));
     if ((rc = dalloc(e, &e->d_hist, S * (size_t)e->cfg.max_model_len, true))) return rc;
     e->h_block_table.assign(2 * S * e->max_blocks, 0);
     HIP_TRY(t3::prepare_kernels());
@@ -452,6 +467,7 @@ extern "C" int t3_add_request(T3Handle e, int64_t req_id, const int32_t* ids, in
     Request r;
     r.id = req_id; r.prompt.assign(ids, ids + T); r.cond.assign(cond, cond + (size_t)T3_COND_ROWS * D); r.sp = *sp;
     r.limit = std::min(sp->max_tokens, e->cfg.max_model_len - T);
+    r.t_add = e->now_s();
     e->reqs.emplace(req_id, std::move(r));
     e->waiting.push_back(req_id);
     return T3_OK;
@@ -476,7 +492,7 @@ static int admit(T3Engine* e) {
         for (int s = 0; s < e->cfg.max_seqs; ++s) if (e->slot_req[s] < 0) { slot = s; break; }
         if (slot < 0 || (int64_t)e->free_blocks.size() < 2 * (int64_t)need) break;
         e->waiting.pop_front();
-        r.slot = slot; r.state = PREFILL; e->slot_req[slot] = r.id;
+        r.slot = slot; r.state = PREFILL; e->slot_req[slot] = r.id; r.t_admit = e->now_s();
         for (int s = 0; s < 2; ++s)
             for (int b = 0; b < need; ++b) {
                 const int blk = e->free_blocks.back(); e->free_blocks.pop_back();
@@ -517,6 +533,7 @@ static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec&
         Prof p(e, K_EMBED, s);
         EmbedArgs ea{g.dm.rows, e->row_stride, e->d_cond, e->text_emb, e->text_pos, e->speech_emb, e->speech_pos, g.h, M, g.dm.out_tok};
         HIP_TRY(launch_embed(ea, s));
+        if (e->d_dbg_emb) HIP_TRY(hipMemcpyAsync(e->d_dbg_emb, g.h, (size_t)M * D * 2, hipMemcpyDeviceToDevice, s));
     }
     const size_t layer_elems = (size_t)e->n_blocks * KV_BLOCK_ELEMS;
     const int max_chunks = (e->cfg.max_model_len + CHUNK - 1) / CHUNK;
@@ -624,6 +641,10 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
         if (sr.M == 0) continue;
         HIP_TRY(hipStreamWaitEvent(g.stream, e->ev_admit, 0));
         HIP_TRY(hipMemcpyAsync(g.d_meta, g.h_meta[buf], g.meta_rows_off + (size_t)sr.M * e->row_stride * 4, hipMemcpyHostToDevice, g.stream));   // sel arrays + the used row records
+        if (e->d_dbg_emb) {
+            e->dbg_emb_rec.resize((size_t)2 * sr.M);
+            for (int r = 0; r < sr.M; ++r) { const int* rec = g.hm[buf].rows + (size_t)r * e->row_stride; e->dbg_emb_rec[2 * r] = rec[0]; e->dbg_emb_rec[2 * r + 1] = rec[1]; }
+        }
         const bool use_graph = !e->cfg.enforce_eager && !e->profile && sr.n_prefill_rows == 0;
         if (use_graph) {
             const auto key = std::make_pair(sr.M, sr.n_sel);
@@ -657,6 +678,18 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
     return T3_OK;
 }
 
+// n more per-utterance device id buffers for the hand-off pool, carved from one allocation
+static int grow_out_pool(T3Engine* e, int n) {
+    const size_t per = (size_t)e->cfg.max_model_len;
+    int32_t* slab = nullptr;
+    const hipError_t me = hipMalloc((void**)&slab, (size_t)n * per * 4);
+    if (me != hipSuccess) return e->fail(T3_E_NOMEM, "hipMalloc of " + std::to_string((size_t)n * per * 4) + " bytes for " + std::to_string(n) +
+                                                     " hand-off id buffers failed: " + hipGetErrorString(me));
+    e->out_slabs.push_back(slab);
+    for (int i = 0; i < n; ++i) e->out_pool.push_back(slab + (size_t)i * per);
+    return T3_OK;
+}
+
 // Wait for an enqueued step, account for it and hand its tokens to the requests.
 static int complete_step(T3Engine* e, T3Engine::Step& st, T3StepResult* res) {
     res->n_rows = st.M_all; res->n_prefill_rows = st.n_prefill_rows; res->n_sampled = st.n_sampled;
@@ -682,7 +715,8 @@ static int complete_step(T3Engine* e, T3Engine::Step& st, T3StepResult* res) {
             e->pev_used[k] = 0;
         }
     }
-    // ---- host bookkeeping
+    // ---- host bookkeeping (a device error met here is reported after the bookkeeping is complete: the scheduler state stays consistent)
+    int dev_rc = T3_OK;
     for (int gi = 0; gi < e->n_groups; ++gi) {
         const T3Engine::StepRec& sr = st.g[gi];
         const int* toks = e->groups[gi].h_out_tok[st.buf];
@@ -693,22 +727,29 @@ static int complete_step(T3Engine* e, T3Engine::Step& st, T3StepResult* res) {
                 continue;
             }
             const int tok = toks[i];
+            if (r.out.empty()) r.t_first = e->now_s();
             r.out.push_back(tok); e->st.tokens_generated++;
             int fin = 0;
             if (!r.sp.ignore_eos && tok == r.sp.stop_token) fin = 1;
             else if ((int)r.out.size() >= r.limit) fin = 2;
             if (fin) {
-                r.state = FINISHED; r.finish_reason = fin;
-                {   // the ids stay on the device for the hand-off: out of the slot's history (the slot will be reused) into a buffer of the request's own.
+                r.state = FINISHED; r.finish_reason = fin; r.t_finish = e->now_s();
+                if (e->keep_device_ids) {
+                    // the ids stay on the device for the hand-off: out of the slot's history (the slot will be reused) into a buffer of the request's own.
                     // Stream order does the rest: the copy runs behind the step that drew the last token and ahead of the slot's next occupant.
-                    if (e->out_pool.empty()) { int32_t* b = nullptr; if (hipMalloc((void**)&b, (size_t)e->cfg.max_model_len * 4) == hipSuccess) e->out_pool.push_back(b); }
+                    if (e->out_pool.empty()) {       // more finished-and-unreleased requests than t3_reserve_handoff was told about
+                        const int grc = grow_out_pool(e, 16);
+                        if (grc && !dev_rc) { dev_rc = grc; }
+                    }
                     if (!e->out_pool.empty()) {
                         r.d_out = e->out_pool.back(); e->out_pool.pop_back();
-                        (void)hipMemcpyAsync(r.d_out, e->d_hist + (size_t)r.slot * e->cfg.max_model_len, r.out.size() * 4, hipMemcpyDeviceToDevice, e->groups[gi].stream);
+                        const hipError_t ce = hipMemcpyAsync(r.d_out, e->d_hist + (size_t)r.slot * e->cfg.max_model_len, r.out.size() * 4, hipMemcpyDeviceToDevice, e->groups[gi].stream);
+                        if (ce != hipSuccess && !dev_rc) dev_rc = e->fail(T3_E_DEVICE, std::string("hand-off copy of a finished utterance's ids failed: ") + hipGetErrorString(ce));
                     }
                 }
                 if (res->n_finished < 64) res->finished_ids[res->n_finished] = r.id;
                 res->n_finished++;
+                e->finished_q.push_back(r.id);
                 if (r.n_sched > (int)r.out.size()) r.zombie = true;     // the step running ahead still uses its slot and KV blocks
                 else release_slot(e, r);
             }
@@ -716,7 +757,7 @@ static int complete_step(T3Engine* e, T3Engine::Step& st, T3StepResult* res) {
     }
     if (res->n_finished) e->running.erase(std::remove_if(e->running.begin(), e->running.end(), [&](int64_t id) { return e->reqs[id].state == FINISHED; }), e->running.end());
     res->n_running = (int)e->running.size(); res->n_waiting = (int)e->waiting.size();
-    return T3_OK;
+    return dev_rc;
 }
 
 static int check_ready(T3Engine* e) {
@@ -786,6 +827,15 @@ extern "C" int t3_get_output(T3Handle e, int64_t req_id, int32_t* ids, int32_t* 
     return T3_OK;
 }
 
+extern "C" int t3_get_timing(T3Handle e, int64_t req_id, double* out4) {
+    if (!e || !out4) return T3_E_INVALID;
+    auto it = e->reqs.find(req_id);
+    if (it == e->reqs.end()) return e->fail(T3_E_NOTFOUND, "unknown request id");
+    const Request& r = it->second;
+    out4[0] = r.t_add; out4[1] = r.t_admit; out4[2] = r.t_first; out4[3] = r.t_finish;
+    return T3_OK;
+}
+
 extern "C" int t3_release_request(T3Handle e, int64_t req_id) {
     if (!e) return T3_E_INVALID;
     auto it = e->reqs.find(req_id);
@@ -806,17 +856,49 @@ extern "C" int t3_handoff_tokens(T3Handle e, const int64_t* req_ids, int32_t n, 
         auto it = e->reqs.find(req_ids[i]);
         if (it == e->reqs.end()) return e->fail(T3_E_NOTFOUND, "unknown request id");
         const Request& r = it->second;
-        if (r.state != FINISHED || (!r.d_out && !r.out.empty())) return e->fail(T3_E_STATE, "request not finished (or its device ids were not kept)");
+        if (r.state != FINISHED) return e->fail(T3_E_STATE, "request " + std::to_string(req_ids[i]) + " has not finished");
+        if (!r.d_out && !r.out.empty()) return e->fail(T3_E_STATE, "the device ids of request " + std::to_string(req_ids[i]) + " were not kept: call t3_reserve_handoff before the run");
         items[i] = HandoffItem{r.d_out, (int)r.out.size(), text_token_counts[i], 0};
     }
-    for (auto& g : e->groups) HIP_TRY(hipStreamSynchronize(g.stream));        // the per-request copies were queued on the group streams
-    HandoffItem* d_items = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_items, items.size() * sizeof(HandoffItem)));
-    hipError_t err = hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(HandoffItem), hipMemcpyHostToDevice, e->stream);
-    if (err == hipSuccess) err = launch_handoff(d_items, n, flags, dev_tokens, ld, dev_lens, e->stream);
-    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
-    (void)hipFree(d_items);
-    HIP_TRY(err);
+    // the per-request copies were queued on the group streams: this launch waits for them on the device, not on the host
+    for (auto& g : e->groups) { HIP_TRY(hipEventRecord(e->ev_handoff, g.stream)); HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_handoff, 0)); }
+    if (n > e->handoff_items_cap) {
+        HIP_TRY(hipStreamSynchronize(e->stream));          // a previous call's launch may still read the old buffer
+        free_dev(e->d_handoff_items); e->d_handoff_items = nullptr; e->handoff_items_cap = 0;
+        const int cap = std::max(n, 2 * e->cfg.max_seqs);
+        if (hipMalloc((void**)&e->d_handoff_items, (size_t)cap * sizeof(HandoffItem)) != hipSuccess) return e->fail(T3_E_NOMEM, "hipMalloc (hand-off argument buffer) failed");
+        e->handoff_items_cap = cap;
+    }
+    HIP_TRY(hipMemcpyAsync(e->d_handoff_items, items.data(), items.size() * sizeof(HandoffItem), hipMemcpyHostToDevice, e->stream));   // pageable source: staged before the call returns
+    HIP_TRY(launch_handoff(e->d_handoff_items, n, flags, dev_tokens, ld, dev_lens, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return T3_OK;
+}
+
+extern "C" int t3_reserve_handoff(T3Handle e, int32_t n_requests) {
+    if (!e || n_requests < 0) return T3_E_INVALID;
+    if (!e->finalized) return e->fail(T3_E_STATE, "finalize_weights first");
+    (void)hipSetDevice(e->cfg.device_id);
+    e->keep_device_ids = n_requests > 0;
+    const int missing = n_requests - (int)e->out_pool.size();
+    return missing > 0 ? grow_out_pool(e, missing) : T3_OK;
+}
+
+extern "C" int t3_pop_finished(T3Handle e, int64_t* ids, int32_t cap) {
+    if (!e || (!ids && cap > 0) || cap < 0) return T3_E_INVALID;
+    int n = 0;
+    while (n < cap && !e->finished_q.empty()) { ids[n++] = e->finished_q.front(); e->finished_q.pop_front(); }
+    return n;
+}
+
+extern "C" int t3_debug_embeddings(T3Handle e, void* out_bf16, int32_t* row_stream, int32_t* row_pos, int32_t* n) {
+    if (!e || !n) return T3_E_INVALID;
+    if (!e->d_dbg_emb) return e->fail(T3_E_STATE, "engine was created without debug_logits (or with several utterance groups)");
+    const int rows = (int)(e->dbg_emb_rec.size() / 2), m = std::min(rows, *n);
+    (void)hipSetDevice(e->cfg.device_id);
+    if (out_bf16 && m > 0) HIP_TRY(hipMemcpy(out_bf16, e->d_dbg_emb, (size_t)m * D * 2, hipMemcpyDeviceToHost));
+    for (int r = 0; r < m; ++r) { if (row_stream) row_stream[r] = e->dbg_emb_rec[2 * r]; if (row_pos) row_pos[r] = e->dbg_emb_rec[2 * r + 1]; }
+    *n = rows;
     return T3_OK;
 }
 

@@ -60,7 +60,7 @@ class T3Stats(ct.Structure):
 # every symbol include/t3_engine.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
     "t3_create", "t3_destroy", "t3_last_error", "t3_load_tensor", "t3_finalize_weights", "t3_add_request",
-    "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_release_request", "t3_abort_request", "t3_handoff_tokens", "t3k_handoff",
+    "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_get_timing", "t3_release_request", "t3_abort_request", "t3_handoff_tokens", "t3_reserve_handoff", "t3_pop_finished", "t3_debug_embeddings", "t3k_handoff",
     "t3_clean_tokens", "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_set_profile_kernel", "t3_kernel_ms",
     "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_decode_attention", "t3k_sample", "t3k_expf",
     "t3_cond_create", "t3_cond_destroy", "t3_cond_last_error", "t3_cond_load_tensor", "t3_cond_encode", "t3_cond_emotion_row",
@@ -102,9 +102,13 @@ def load_library():
     L.t3_run_steps.argtypes = [vp, i32, ct.POINTER(i32)]
     L.t3_num_unfinished.argtypes = [vp]
     L.t3_get_output.argtypes = [vp, i64, vp, ct.POINTER(i32), ct.POINTER(i32)]
+    L.t3_get_timing.argtypes = [vp, i64, vp]
     L.t3_release_request.argtypes = [vp, i64]
     L.t3_abort_request.argtypes = [vp, i64]
     L.t3_handoff_tokens.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]
+    L.t3_reserve_handoff.argtypes = [vp, i32]
+    L.t3_pop_finished.argtypes = [vp, vp, i32]
+    L.t3_debug_embeddings.argtypes = [vp, vp, vp, vp, ct.POINTER(i32)]
     L.t3k_handoff.argtypes = [vp, i32, i32, i32, vp, i32, ct.POINTER(i32)]
     L.t3_clean_tokens.argtypes = [vp, i32, i32, i32, vp, ct.POINTER(i32)]
     L.t3_debug_logits.argtypes = [vp, i64, vp]
@@ -243,6 +247,12 @@ class T3Engine:
         self._chk(self.lib.t3_get_output(self.h, int(req_id), ct.c_void_p(buf.ctypes.data), ct.byref(n), ct.byref(fr)))
         return buf[: n.value].tolist(), int(fr.value)
 
+    def timing(self, req_id: int) -> Tuple[float, float, float, float]:
+        """(added, admitted, first token, finished) in seconds since the engine was created"""
+        t = (ct.c_double * 4)()
+        self._chk(self.lib.t3_get_timing(self.h, int(req_id), t))
+        return tuple(float(x) for x in t)
+
     def release(self, req_id: int):
         self._chk(self.lib.t3_release_request(self.h, int(req_id)))
 
@@ -264,6 +274,28 @@ class T3Engine:
         self._chk(self.lib.t3_handoff_tokens(self.h, ct.c_void_p(rid.ctypes.data), n, ct.c_void_p(tc.ctypes.data), int(bool(range_filter)),
                                              ct.c_void_p(toks.data_ptr()), ld, ct.c_void_p(lens.data_ptr())))
         return toks, lens
+
+    def reserve_handoff(self, n_requests: int):
+        """Keep finished utterances' ids in device memory (n_requests > 0: buffers for that many are made now) or stop doing so (0)."""
+        self._chk(self.lib.t3_reserve_handoff(self.h, int(n_requests)))
+
+    def pop_finished(self, cap: int = 4096) -> List[int]:
+        """ids of the requests that finished since the last call, oldest first"""
+        buf = np.zeros(max(1, cap), dtype=np.int64)
+        n = int(self.lib.t3_pop_finished(self.h, ct.c_void_p(buf.ctypes.data), int(cap)))
+        if n < 0:
+            self._chk(n)
+        return buf[:n].tolist()
+
+    def debug_embeddings(self):
+        """(rows [n, 1024] bf16, streams [n], positions [n]) of the most recent step's embedded input rows (debug_logits engines)."""
+        n = ct.c_int32(0)
+        self._chk(self.lib.t3_debug_embeddings(self.h, None, None, None, ct.byref(n)))
+        rows = int(n.value)
+        out = torch.empty(rows, C.HIDDEN, dtype=torch.bfloat16); rs = np.zeros(rows, dtype=np.int32); rp = np.zeros(rows, dtype=np.int32)
+        n = ct.c_int32(rows)
+        self._chk(self.lib.t3_debug_embeddings(self.h, ct.c_void_p(out.data_ptr()), ct.c_void_p(rs.ctypes.data), ct.c_void_p(rp.ctypes.data), ct.byref(n)))
+        return out, rs, rp
 
     def abort(self, req_id: int):
         """Drop a request in any state (a waiting one leaves the queue, a running one frees its slot and KV blocks)."""

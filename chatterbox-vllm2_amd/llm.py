@@ -110,6 +110,8 @@ class LLM:
         self.max_model_len, self.seed = int(max_model_len), int(seed)
         if device_id is None:
             device_id = int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.device_count() > 1 else 0
+        if torch.cuda.is_available():
+            torch.cuda.set_device(device_id)      # torch-side work of this process (RCCL collectives of dp.py, hand-off tensors) runs on the engine's GPU
         # enforce_eager: in vLLM it switches off CUDA-graph capture and torch.compile (start-up time and memory knobs; the
         # reference server always passes True, api_server.py:157 -> tts.py:156,163).  Here a decode step is replayed from a
         # hipGraph captured on first use -- no compile step, a few MB -- and token ids do not depend on it, so the flag is
@@ -157,9 +159,10 @@ class LLM:
           * no SamplingParams.seed (what tts.py:455-464 does): every request takes the next RNG stream of this LLM object, so the
             same text submitted twice gives two different utterances, while a fresh process replays the same sequence -- vLLM's
             behaviour with its global `seed=0` default;
-          * SamplingParams.seed given: that request is reproducible wherever it sits (vLLM's per-request generator);
+          * SamplingParams.seed given: that request is reproducible wherever it sits -- alone, in a batch, in a data-parallel shard
+            (vLLM's per-request generator): it draws from (seed, stream 0) whatever uids / uid_base say;
           * uids (one per prompt) or uid_base (request i uses uid_base + i) given -- the data-parallel launcher, dp.py: the stream
-            is the utterance's GLOBAL index, so a sharded run emits the ids of the one-GPU run.
+            of an UNSEEDED request is the utterance's GLOBAL index, so a sharded run emits the ids of the one-GPU run.
         keep_for_handoff: the requests stay in the engine (finished) until `handoff_tokens(outputs, ...)` hands their ids to the
         vocoder from device memory; without it they are released here, as the reference's flow expects."""
         if isinstance(prompts, (str, dict)):
@@ -176,6 +179,9 @@ class LLM:
         metas = []
         queued: List[int] = []
         uid0 = self._next_uid
+        # ids stay in device memory for the hand-off only when asked for; free buffers for this call's requests are made now, outside
+        # the step loop (requests kept by an earlier call hold theirs until handoff_tokens releases them)
+        self.engine.reserve_handoff(len(prompts) if keep_for_handoff else 0)
         try:
             self._queue(prompts, sps, uids, metas, queued)
         except Exception:
@@ -228,10 +234,10 @@ class LLM:
                     raise ValueError("the T3 engine supports one stop token id")
                 stop = int(sp.stop_token_ids[0]) - C.SPEECH_TOKEN_OFFSET          # 9062 -> 6562 (tts.py:458)
             max_tokens = sp.max_tokens if sp.max_tokens is not None else self.max_model_len
-            if uids is not None:
+            if sp.seed is not None:
+                uid = 0                    # a seeded request draws from (seed, 0) wherever it runs: alone, in a batch or in a data-parallel shard
+            elif uids is not None:
                 uid = int(uids[i])
-            elif sp.seed is not None:
-                uid = 0
             else:
                 uid = self._next_uid; self._next_uid += 1
             esp = make_sampling(temperature=sp.temperature, top_p=sp.top_p, min_p=sp.min_p, repetition_penalty=sp.repetition_penalty,

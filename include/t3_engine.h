@@ -82,7 +82,7 @@ typedef struct {
     int32_t n_finished;        /* finished this step */
     int32_t n_running;         /* after the step */
     int32_t n_waiting;
-    int64_t finished_ids[64];  /* first min(n_finished, 64) */
+    int64_t finished_ids[64];  /* first min(n_finished, 64); every finished id, in order, is also queued for t3_pop_finished */
 } T3StepResult;
 
 typedef struct {
@@ -122,9 +122,18 @@ int t3_run_until_done(T3Handle h);               /* C++ loop, no Python per step
 /* Runs at most n steps (stops early when nothing is left); *done = steps actually run. */
 int t3_run_steps(T3Handle h, int32_t n, int32_t* done);
 int t3_num_unfinished(T3Handle h);
+/* Ids of the requests that finished since the previous call (any of t3_step / t3_run_steps / t3_run_until_done), oldest first:
+ * up to `cap` of them are written to ids and leave the queue.  Returns how many were written (a step of 128 utterances can retire
+ * more than the 64 that fit T3StepResult), or a negative T3_E_* code.  vLLM hands finished RequestOutputs back from every
+ * engine step (LLM.generate collects them, tts.py:445-465); this is that stream of ids. */
+int t3_pop_finished(T3Handle h, int64_t* ids, int32_t cap);
 /* ids: offset-space token ids (>= 2500), the stop id included when hit.
  * On entry *n = capacity; on exit *n = number of tokens.  finish_reason: 0 running, 1 stop, 2 length. */
 int t3_get_output(T3Handle h, int64_t req_id, int32_t* ids, int32_t* n, int32_t* finish_reason);
+/* Host wall-clock marks of a request, seconds since t3_create: out4 = {added (t3_add_request), admitted (slot + KV blocks
+ * granted), first token read back, finished}; 0 where not reached yet.  The reference's clock is the wall time of its
+ * `self.t3.generate` call (tts.py:444,466-467); per request, RTF = (finished - admitted) / (n_tokens / 25). */
+int t3_get_timing(T3Handle h, int64_t req_id, double* out4);
 int t3_release_request(T3Handle h, int64_t req_id);   /* forget a finished request */
 /* Drop a request in any state -- vLLM's abort_request: a WAITING one leaves the queue, a running one gives its slot and KV
  * blocks back -- and forget it.  The host mirror uses it to roll back a generate() call whose later prompt was rejected
@@ -155,11 +164,21 @@ int t3_clean_tokens(const int32_t* speech_ids, int32_t n, int32_t text_token_cou
  * ready (the call synchronises its own stream).                                                                        */
 int t3_handoff_tokens(T3Handle h, const int64_t* req_ids, int32_t n, const int32_t* text_token_counts, int32_t flags,
                       int32_t* dev_tokens, int32_t ld, int32_t* dev_lens);
+/* Switches the retention of finished utterances' ids in device memory on (n_requests > 0) or off (0; the default: a caller
+ * that reads ids with t3_get_output pays nothing for the hand-off), and makes sure buffers for n_requests finished-and-unreleased
+ * utterances exist BEFORE the step loop runs (max_model_len int32 each).  If more than that finish unreleased, the pool grows inside
+ * the loop and an allocation failure there is reported by the step call (T3_E_NOMEM), not by a later t3_handoff_tokens. */
+int t3_reserve_handoff(T3Handle h, int32_t n_requests);
 
 /* ---- parity / measurement hooks --------------------------------------------------------- */
 /* post-CFG logits [8194] (speech-space, before the 2500-wide -inf pad of t3.py:669-672) of the
  * most recent sampled step of req_id; needs cfg.debug_logits = 1. */
 int t3_debug_logits(T3Handle h, int64_t req_id, float* out_8194);
+/* The embedded input rows of the most recent step -- what get_input_embeddings (t3.py:424-647) hands to the Llama blocks: cond /
+ * text + position / zero / speech + position rows, bf16 [rows][1024] -- with every row's stream (2 * slot for the conditional
+ * half, 2 * slot + 1 for the unconditional half of the reference's [N, 2048] layout) and position; needs cfg.debug_logits = 1.
+ * On entry *n = capacity in rows (out_bf16 / row_stream / row_pos may be NULL); on exit *n = rows of the step. */
+int t3_debug_embeddings(T3Handle h, void* out_bf16, int32_t* row_stream, int32_t* row_pos, int32_t* n);
 int t3_stats(T3Handle h, T3Stats* out);
 int t3_reset_stats(T3Handle h);
 /* Average duration (ms) per launch of each kernel class over decode-only steps since the last reset,

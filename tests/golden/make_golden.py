@@ -7,6 +7,9 @@ What comes from where:
   G1  cond_enc.npz     -- output of the REFERENCE's own T3CondEnc (+Perceiver, LearnedPositionEmbeddings),
                           imported from /root/reference with stub parent packages (the package
                           __init__ files import vllm, which is not installed), seeded weights + inputs.
+  G2  prompt_embeds.npz -- outputs of the reference's own models/t3/t3.py: create_triangular_matrix, split_prefill_decode and the
+                          prefill branches of get_input_embeddings (full block + the three chunked variants), and what its decode
+                          branch literally returns; t3.py imported with raise-on-use placeholders for the vllm names it imports.
   G3  rope.npz         -- inv_freq and cos/sin of transformers' LlamaRotaryEmbedding for the reference's
                           t3-model/config.json rope settings.
   G5/G6 streams.npz    -- oracle token streams + post-CFG logits on seeded synthetic weights
@@ -294,6 +297,192 @@ def g6c_full_length_streams():
     m.close()
     print("G6c full-length streams:", {k: v.shape for k, v in out.items()})
 
+# ------------------------------------------------------------------------------------------------------------------------
+# G2: fixtures produced by the reference's OWN hot-path code (models/t3/t3.py), not by a restatement of it
+# ------------------------------------------------------------------------------------------------------------------------
+class _Seal:
+    sealed = False          # False while t3.py is being imported; True while a fixture case runs
+    touched = []            # placeholder uses seen while sealed (must stay empty)
+
+
+class _PlaceholderMeta(type):
+    """Classes standing in for the vllm names t3.py imports (t3.py:9-31).  They exist so that the module's `import` lines, base-class
+    lists, annotations and its registration decorator (t3.py:252-254) evaluate; once sealed, ANY use of one -- a call, an
+    instantiation, a subscript, an attribute -- raises, so a fixture case cannot have executed a line that depends on vllm."""
+    def _guard(cls, what):
+        if _Seal.sealed:
+            _Seal.touched.append(f"{cls.__name__}: {what}")
+            raise AssertionError(f"fixture case touched the vllm placeholder {cls.__name__} ({what})")
+
+    def __call__(cls, *a, **k):
+        if not cls.__dict__.get("_placeholder"):
+            # a class of t3.py that merely inherits from a placeholder: instantiating it would run vllm's base-class machinery
+            cls._guard("instantiation of a class derived from a placeholder")
+            return super().__call__(*a, **k)
+        cls._guard("call")
+        return lambda obj=None, *aa, **kk: obj          # import time only: `@MULTIMODAL_REGISTRY.register_processor(...)` returns the class unchanged
+
+    def __getitem__(cls, item):
+        cls._guard("subscript")
+        return cls
+
+    def __getattr__(cls, name):
+        if name.startswith("__") or not cls.__dict__.get("_placeholder"):
+            raise AttributeError(name)
+        cls._guard(f"attribute {name}")
+        return _PlaceholderMeta(f"{cls.__name__}.{name}", (), {"_placeholder": True})
+
+
+class _PlaceholderModule(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        if _Seal.sealed:
+            _Seal.touched.append(f"{self.__name__}.{name}")
+            raise AssertionError(f"fixture case touched the vllm placeholder module {self.__name__}.{name}")
+        ph = _PlaceholderMeta(name, (), {"_placeholder": True})
+        setattr(self, name, ph)
+        return ph
+
+
+VLLM_MODULES = ("vllm", "vllm.config", "vllm.model_executor", "vllm.model_executor.layers", "vllm.model_executor.layers.logits_processor",
+                "vllm.model_executor.layers.vocab_parallel_embedding", "vllm.model_executor.models", "vllm.model_executor.models.interfaces",
+                "vllm.model_executor.models.interfaces_base", "vllm.model_executor.models.llama", "vllm.model_executor.sampling_metadata",
+                "vllm.multimodal", "vllm.multimodal.inputs", "vllm.multimodal.parse", "vllm.multimodal.processing", "vllm.multimodal.profiling",
+                "vllm.sequence")
+
+
+def import_reference_t3():
+    """models/t3/t3.py of the reference, imported in place.  vllm is not installed (ModuleNotFoundError, nothing was refused): the
+    names t3.py imports from it are placeholder classes that raise on any use once the import is over (_PlaceholderMeta)."""
+    import importlib
+    import_reference_leaf_modules()
+    assert importlib.util.find_spec("vllm") is None or isinstance(sys.modules.get("vllm"), _PlaceholderModule), "a real vllm is importable: use it instead"
+    for name in VLLM_MODULES:
+        m = _PlaceholderModule(name); m.__path__ = []; sys.modules[name] = m
+    _Seal.sealed = False
+    t3 = importlib.import_module("chatterbox_vllm.models.t3.t3")
+    _Seal.sealed = True
+    return t3
+
+
+def _crc_rows(t: torch.Tensor) -> np.ndarray:
+    """CRC-32 of every row's bytes (bf16 rows of 2048 -> 4096 bytes): a compact bit-exact pin for long prompts"""
+    import zlib
+    b = t.contiguous().view(torch.int16).numpy()
+    return np.array([zlib.crc32(b[i].tobytes()) for i in range(b.shape[0])], dtype=np.uint32)
+
+
+def g2_prompt_embeds():
+    """prompt_embeds.npz -- OUTPUTS OF THE REFERENCE'S OWN CODE on the path's front end:
+      * create_triangular_matrix (t3.py:94-102);
+      * T3VllmModel.split_prefill_decode (t3.py:340-421) on a step's flat id vector (two prefill blocks back to back);
+      * T3VllmModel.get_input_embeddings, prefill branches (t3.py:542-561 full block; :562-582 start-only chunk; :583-611 end chunk with
+        the tail of the conditioning; :612-632 end chunk without conditioning, text positions from the triangular rows), bf16 modules as
+        vLLM holds them (config.json torch_dtype), fp32 multimodal tensor as tts.py:286 hands it over;
+      * what its decode branch (t3.py:440-486) literally returns for N = 1 and N = 2.
+    The model object is made with T3VllmModel.__new__ + nn.Module.__init__ (its __init__ builds vllm's LlamaModel); the five attributes
+    the methods read are set as t3.py:270-284 and :325-330 do, from the product's seeded synthetic checkpoint.  T3MultiModalProcessor.apply
+    (t3.py:143-249, the id layout of :189-200) cannot run without vllm's processor base class: the id vectors below are built HERE from the
+    module's own constants; only the triangular matrix comes from reference code."""
+    import torch.nn as nn
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb, synthetic_tensors
+    t3 = import_reference_t3()
+    assert not _Seal.touched
+    lpe = sys.modules["chatterbox_vllm.models.t3.modules.learned_pos_emb"]
+    cfg = sys.modules["chatterbox_vllm.models.t3.modules.t3_config"]
+    tok = json.load(open(os.path.join(HERE, "tokenizer.json")))
+    cond = synthetic_cond_emb(1)                                        # fp32 CPU tensor, as tts.py:286 ships it
+    NC, OFF = t3.CONDITIONING_SIZE, t3.SPEECH_TOKEN_OFFSET
+    out = {"constants": np.array([t3.PREFILL_COND_START_TOKEN, t3.PREFILL_COND_END_TOKEN, t3.PREFILL_END_TOKEN, NC, OFF], np.int32)}
+
+    def model(vocab):
+        w = {k: v for k, v in synthetic_tensors(1, vocab, 1234) if not k.startswith("tfmr.")}
+        m = t3.T3VllmModel.__new__(t3.T3VllmModel)
+        nn.Module.__init__(m)
+        m.t3conf = cfg.T3Config(); m.dim = m.t3conf.n_channels                                  # t3.py:273-274
+        m.text_emb = nn.Embedding(vocab, m.dim); m.speech_emb = nn.Embedding(m.t3conf.speech_tokens_dict_size, m.dim)   # :276-277
+        m.text_pos_emb = lpe.LearnedPositionEmbeddings(m.t3conf.max_text_tokens + 2, m.dim)     # :280-281
+        m.speech_pos_emb = lpe.LearnedPositionEmbeddings(m.t3conf.max_speech_tokens + 2 + 2, m.dim)   # :283-284
+        m.to(torch.bfloat16)
+        m.text_emb.load_state_dict({"weight": w["text_emb.weight"]}); m.speech_emb.load_state_dict({"weight": w["speech_emb.weight"]})
+        m.text_pos_emb.load_state_dict({"emb.weight": w["text_pos_emb.emb.weight"]}); m.speech_pos_emb.load_state_dict({"emb.weight": w["speech_pos_emb.emb.weight"]})
+        m.precomputed_text_pos_emb = m.text_pos_emb.get_fixed_embedding(torch.arange(m.t3conf.max_text_tokens + 2))[0]             # :325-326
+        m.precomputed_speech_pos_emb = m.speech_pos_emb.get_fixed_embedding(torch.arange(m.t3conf.max_speech_tokens + 2 + 2))[0]   # :329-330
+        return m.eval()
+
+    def ids_and_mm(text_ids):
+        ids = [t3.PREFILL_COND_START_TOKEN] + [text_ids[0]] * (NC - 2) + [t3.PREFILL_COND_END_TOKEN] + list(text_ids) + [t3.PREFILL_END_TOKEN]
+        mm = torch.cat([cond, t3.create_triangular_matrix(len(text_ids), cond.shape[1]), torch.zeros(1, cond.shape[1])], dim=0)   # t3.py:212-221
+        assert len(ids) == mm.shape[0]
+        return torch.tensor(ids), mm
+
+    tri = t3.create_triangular_matrix(5, 7)
+    out["tri_5x7"] = tri.numpy()
+    with torch.no_grad():
+        # ---- full blocks of the three BASELINE prompts: per-row CRC-32 of the [T, 2048] output (cast to bf16 as vLLM's input buffer holds it)
+        for key, vocab in (("en_english_ids", 704), ("en_mtl_ids", 2454), ("es_mtl_ids", 2454)):
+            m = model(vocab)
+            ids, mm = ids_and_mm(tok[key])
+            y = m.get_input_embeddings(ids, [mm])
+            assert tuple(y.shape) == (len(ids), 2048)
+            out[f"full_{key}_crc"] = _crc_rows(y.to(torch.bfloat16)); out[f"full_{key}_dtype"] = np.array(str(y.dtype))
+        # ---- a short prompt (11 text ids, T = 46), stored in full, and every two-chunk split of it the reference's branches cover
+        m = model(2454)
+        text = [635] + [int(x) for x in np.random.RandomState(2).randint(0, 2454, size=9)] + [0]
+        ids, mm = ids_and_mm(text)
+        T = len(ids)
+        y = m.get_input_embeddings(ids, [mm])
+        out["short_text_ids"] = np.array(text, np.int32); out["short_ids"] = ids.numpy().astype(np.int32)
+        out["short_full"] = y.to(torch.bfloat16).view(torch.int16).numpy(); out["short_full_dtype"] = np.array(str(y.dtype))
+        for k in (1, 10, 33, 34, 35, 40, T - 1):                        # chunk A = rows [0, k), chunk B = rows [k, T)
+            ya = m.get_input_embeddings(ids[:k], [mm[:k]]); yb = m.get_input_embeddings(ids[k:], [mm[k:]])
+            assert ya.shape[0] == k and yb.shape[0] == T - k
+            out[f"short_split{k}_a_crc"] = _crc_rows(ya.to(torch.bfloat16)); out[f"short_split{k}_b_crc"] = _crc_rows(yb.to(torch.bfloat16))
+        # ---- split_prefill_decode on a flat step vector: two full prefill blocks back to back (a new block starts at every 695)
+        ids2, mm2 = ids_and_mm([708, 5, 6, 0])
+        flat = torch.cat([ids, ids2]); parts = m.split_prefill_decode(flat, [mm, mm2])
+        out["split_lengths"] = np.array([len(p[0]) for p in parts], np.int32)
+        out["split_mm_rows"] = np.array([-1 if p[1] is None else p[1].shape[0] for p in parts], np.int32)
+        yy = m.get_input_embeddings(flat, [mm, mm2])
+        out["two_blocks_crc"] = _crc_rows(yy.to(torch.bfloat16))
+        # a decode run between them (ids >= 2500, no multimodal rows): how the function segments it
+        flat3 = torch.cat([ids, torch.tensor([OFF + 17]), ids2]); parts3 = m.split_prefill_decode(flat3, [mm, mm2])
+        out["split3_lengths"] = np.array([len(p[0]) for p in parts3], np.int32)
+        out["split3_is_decode"] = np.array([p[1] is None for p in parts3], np.int32)
+        # ---- the decode branch as written (SURVEY.md 9 Q1): N = 1 -> a [1, 2048, 1024] tensor whose [0, j, :] is speech_emb[id] + speech_pos[j]
+        # for j < 1024 (seq_len is read from the channel dimension), twice along dim 1; N = 2 -> a broadcast error
+        tok_id = 4242
+        d1 = m.get_input_embeddings(torch.tensor([OFF + tok_id]), None)
+        out["decode_n1_shape"] = np.array(d1.shape, np.int32)
+        out["decode_n1_row0"] = d1[0, 0].to(torch.bfloat16).view(torch.int16).numpy()            # = speech_emb[id] + speech_pos[0]: pos_policy = 1
+        out["decode_n1_row5"] = d1[0, 5].to(torch.bfloat16).view(torch.int16).numpy()            # = speech_emb[id] + speech_pos[5]
+        out["decode_n1_second_half_equal"] = np.array(bool(torch.equal(d1[0, :1024], d1[0, 1024:])))
+        out["decode_token"] = np.array(tok_id, np.int32)
+        try:
+            m.get_input_embeddings(torch.tensor([OFF + 1, OFF + 2]), None)
+            out["decode_n2_error"] = np.array("")
+        except RuntimeError as ex:
+            out["decode_n2_error"] = np.array(type(ex).__name__)
+        # ---- decode rows of a real stream: the short prompt decoded greedily by the ORACLE (1 layer, both position policies); for the
+        # token fed back at step k the reference's decode branch gives [0, 0, :] (its literal index-0 fallback = pos_policy 1) and
+        # [0, k, :] (= speech_emb[tok] + speech_pos[k], the exact per-sequence position = pos_policy 0), each twice along dim 1
+        from oracle import oracle as O
+        om = O.OracleModel(1, 2454, max_pos=128).load(synthetic_tensors(1, 2454, 1234))
+        for pol in (0, 1):
+            gids, _ = om.generate(ids.tolist(), cond, O.make_sampling(temperature=0.0, repetition_penalty=1.0, max_tokens=5, ignore_eos=True, pos_policy=pol), max_model_len=128)
+            out[f"short_greedy_ids_policy{pol}"] = np.array(gids, np.int32)
+            rows = []
+            for k in range(1, 5):                                        # decode step k embeds token k - 1 of the stream
+                d = m.get_input_embeddings(torch.tensor([OFF + gids[k - 1]]), None)
+                row = d[0, k if pol == 0 else 0].to(torch.bfloat16)
+                rows.append(torch.cat([row, row]))
+            out[f"short_decode_rows_policy{pol}_crc"] = _crc_rows(torch.stack(rows))
+        om.close()
+    assert not _Seal.touched, _Seal.touched                              # no executed line of any case above depended on vllm
+    np.savez_compressed(os.path.join(HERE, "prompt_embeds.npz"), **out)
+    print("G2 prompt_embeds:", {k: (v.shape if v.ndim else v.item()) for k, v in out.items() if "crc" not in k})
+
 
 def g8_postfilter():
     """Decisions of the reference's AlignmentStreamAnalyzer (imported; run on CPU) driven by the loop of tts.py:329-350."""
@@ -332,7 +521,7 @@ def g8_postfilter():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1b", "g3", "g7", "g7b", "g6", "g8", "g9", "g6b"]
+    which = sys.argv[1:] or ["g1", "g1b", "g2", "g3", "g7", "g7b", "g6", "g8", "g9", "g6b"]
     if "g1" in which: g1_cond_enc()
     if "g1b" in which: g1b_cond_enc_synthetic()
     if "g3" in which: g3_rope()
@@ -342,4 +531,5 @@ if __name__ == "__main__":
     if "g8" in which: g8_postfilter()
     if "g9" in which: g9_c4_requests()
     if "g6b" in which: g6b_streams_30_layers_multilingual()
+    if "g2" in which: g2_prompt_embeds()
     if "g6c" in which: g6c_full_length_streams()          # not in the default list: about an hour of CPU

@@ -369,11 +369,12 @@ cond = synthetic_cond_emb(1)
 llm = LLM(model="", tokenizer="EnTokenizer", load_format="dummy", num_hidden_layers=2, max_model_len=200, max_num_seqs=4, kv_cache_bytes=1 << 28,
           enforce_eager=False, device_id=0)
 prompts = [{"prompt_token_ids": make_prompt(6 + 3 * i, seed=40 + i)[34:-1], "multi_modal_data": {"conditionals": [cond]}} for i in range(7)]
-sps = [SamplingParams(temperature=0.8, top_p=0.8, repetition_penalty=2.0, max_tokens=12 + 5 * (i % 3), ignore_eos=True) for i in range(7)]
+sps = [SamplingParams(temperature=0.8, top_p=0.8, repetition_penalty=2.0, max_tokens=12 + 5 * (i % 3), ignore_eos=True, seed=(77 if i == 3 else None)) for i in range(7)]
 res = generate_data_parallel(llm, prompts, sps, rank, world)
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
 print("RESULT " + json.dumps(res))
+print("SEEDED " + json.dumps(llm.generate([prompts[3]], [sps[3]])[0].outputs[0].token_ids))      # the seeded request on its own
 llm.shutdown()
 '''
 
@@ -389,7 +390,11 @@ def test_data_parallel_llm_world2_equals_world1(tmp_path):
         procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
         outs = [p.communicate(timeout=600)[0].decode() for p in procs]
         assert all(p.returncode == 0 for p in procs), outs
-        return [json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][-1][7:]) for o in outs]
+        seeded = [json.loads([l for l in o.splitlines() if l.startswith("SEEDED ")][-1][7:]) for o in outs]
+        res = [json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][-1][7:]) for o in outs]
+        for r, sd in zip(res, seeded):
+            assert r[3] == sd, "a seeded request must give the same ids through generate_data_parallel and through LLM.generate"
+        return res
     one = run(1, 29571)[0]
     two = run(2, 29572)
     assert two[0] == one and two[1] == one
@@ -417,3 +422,42 @@ def test_handoff_keeps_ids_on_the_device(E, cond):
     with pytest.raises(E.T3Error):
         llm.engine.handoff_tokens([int(outs[0].request_id)], [4])                              # released by the hand-off
     llm.shutdown()
+
+
+def test_pop_finished_enumerates_more_than_a_step_result_holds(E, tiny_weights, cond):
+    """T3StepResult carries the first 64 finished ids of a step; a 128-utterance step can retire more: t3_pop_finished hands out all of
+    them, in order, once."""
+    eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=64, max_seqs=80, kv_bytes=1 << 30, max_batched_rows=8192)
+    eng.load_tensors(tiny_weights); eng.finalize()
+    for i in range(80):
+        eng.add_request(1000 + i, make_prompt(6, seed=i), cond, E.make_sampling(temperature=0.0, max_tokens=1, ignore_eos=True))
+    r = eng.step()                                               # every prompt prefills in this step and samples its only token
+    assert r.n_finished == 80 and r.n_sampled == 80 and list(r.finished_ids[:64]) == [1000 + i for i in range(64)]
+    assert eng.pop_finished(50) == [1000 + i for i in range(50)]
+    assert eng.pop_finished() == [1000 + i for i in range(50, 80)]
+    assert eng.pop_finished() == []
+    for i in range(80):
+        assert len(eng.get_output(1000 + i)[0]) == 1
+        eng.release(1000 + i)
+    eng.close()
+
+
+def test_handoff_needs_reservation_and_says_so(E, tiny_weights, cond):
+    """Device-resident ids are kept only after t3_reserve_handoff (the default path pays nothing for the hand-off); asking for a
+    hand-off without it names the cause, and reserving fewer buffers than utterances finish still works (the pool grows)."""
+    eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=128, max_seqs=4, kv_bytes=1 << 28)
+    eng.load_tensors(tiny_weights); eng.finalize()
+    sp = E.make_sampling(temperature=0.0, max_tokens=6, ignore_eos=True)
+    eng.add_request(0, make_prompt(6, seed=1), cond, sp); eng.run_until_done()
+    with pytest.raises(E.T3Error, match="reserve_handoff"):
+        eng.handoff_tokens([0], [4])
+    eng.release(0)
+    eng.reserve_handoff(1)
+    for i in range(1, 6):
+        eng.add_request(i, make_prompt(6 + i, seed=i), cond, sp)
+    eng.run_until_done()
+    toks, lens = eng.handoff_tokens(list(range(1, 6)), [40] * 5, range_filter=False)
+    for i in range(1, 6):
+        assert toks[i - 1, : int(lens[i - 1])].tolist() == [t - 2500 for t in eng.get_output(i)[0]][: int(lens[i - 1])] and int(lens[i - 1]) > 0
+        eng.release(i)
+    eng.close()
