@@ -8,6 +8,7 @@
 // split_prefill_decode (t3.py:340-421) has no equivalent here: the scheduler knows which rows are
 // prefill and which are decode.
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -120,6 +121,15 @@ struct T3Engine {
         std::chrono::steady_clock::time_point t_begin;
     };
     std::vector<Group> groups;
+    // Two-track ("antiphase") decode steps: with two utterance groups a decode-only step is ONE graph in which the groups' kernel chains
+    // run on parallel branches, and the HBM-bound attention launches alternate between them (A(L) -> B(L) -> A(L+1) ...): while one
+    // track's attention streams its K/V, the other track's latency-bound GEMM chain runs beside it.  Everything of a step is ordered on
+    // groups[0].stream; the second branch joins it inside the graph.
+    bool antiphase = false;
+    hipStream_t side_stream = nullptr;                   // the second track's branch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> ev_att;                      // [layer][track]: that track's attention of that layer has finished
+    std::map<std::array<int, 4>, hipGraphExec_t> graphs2;   // (M0, n_sel0, M1, n_sel1) -> captured two-track decode step
     unsigned step_seq = 0;
     bool run_ahead = true;     // t3_run_steps / t3_run_until_done enqueue step N+1 before reading step N's tokens
     int64_t graph_captures = 0; double graph_capture_ms = 0;      // T3_GRAPH_STATS=1 prints them at destroy
@@ -198,6 +208,8 @@ extern "C" int t3_create(const T3EngineConfig* cfg, T3Handle* out) {
         e->groups.resize(e->n_groups);
         if (const char* ev = getenv("T3_FUSE_ROPE")) e->fuse_rope = atoi(ev) != 0;
         if (const char* ev = getenv("T3_RUN_AHEAD")) e->run_ahead = atoi(ev) != 0;
+        e->antiphase = e->n_groups == 2;
+        if (const char* ev = getenv("T3_ANTIPHASE")) e->antiphase = atoi(ev) != 0 && e->n_groups == 2;
     }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail_create(T3_E_DEVICE, "hipStreamCreate failed"); }
     hipEventCreate(&e->ev0); hipEventCreate(&e->ev1); hipEventCreateWithFlags(&e->ev_admit, hipEventDisableTiming);
@@ -230,6 +242,11 @@ extern "C" int t3_destroy(T3Handle e) {
         }
         if (g.stream) (void)hipStreamDestroy(g.stream);
     }
+    for (auto& kv : e->graphs2) (void)hipGraphExecDestroy(kv.second);
+    for (auto ev : e->ev_att) (void)hipEventDestroy(ev);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
     free_dev(e->d_cond); free_dev(e->d_counts); free_dev(e->d_sp); free_dev(e->d_dbg); free_dev(e->d_hist);
     for (void* b : e->out_slabs) free_dev(b);      // every hand-off buffer (pooled or held by a request) lives in one of these
     free_dev(e->d_handoff_items); free_dev(e->d_dbg_emb);
@@ -414,6 +431,12 @@ extern "C" int t3_finalize_weights(T3Handle e) {
     if (e->cfg.debug_logits && (rc = dalloc(e, &e->d_dbg, S * V, true))) return rc;
     if (e->cfg.debug_logits && e->n_groups == 1 && (rc = dalloc(e, &e->d_dbg_emb, (size_t)e->groups[0].rcap * D, true))) return rc;
     HIP_TRY(hipEventCreateWithFlags(&e->ev_handoff, hipEventDisableTiming));
+    if (e->antiphase) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        e->ev_att.resize((size_t)2 * e->cfg.n_layers);
+        for (auto& ev : e->ev_att) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
     if ((rc = dalloc(e, &e->d_hist, S * (size_t)e->cfg.max_model_len, true))) return rc;
     e->h_block_table.assign(2 * S * e->max_blocks, 0);
     HIP_TRY(t3::prepare_kernels());
@@ -525,50 +548,94 @@ struct Prof {
     ~Prof() { if (on) hipEventRecord(b, st); }
 };
 
-// One group's kernel sequence for one step (eager, or recorded into a hipGraph by the caller).
-static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr) {
-    hipStream_t s = g.stream;
-    const int M = sr.M, n_sel = sr.n_sel;
-    {
-        Prof p(e, K_EMBED, s);
-        EmbedArgs ea{g.dm.rows, e->row_stride, e->d_cond, e->text_emb, e->text_pos, e->speech_emb, e->speech_pos, g.h, M, g.dm.out_tok};
-        HIP_TRY(launch_embed(ea, s));
-        if (e->d_dbg_emb) HIP_TRY(hipMemcpyAsync(e->d_dbg_emb, g.h, (size_t)M * D * 2, hipMemcpyDeviceToDevice, s));
-    }
+// One group's kernel sequence for one step, in phases (eager, or recorded into a hipGraph by the caller): embed | per layer: qkv,
+// attention (RoPE / KV write fused for decode rows), o + gate/up + down | head + sampler.
+static int launch_embed_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, hipStream_t s) {
+    Prof p(e, K_EMBED, s);
+    EmbedArgs ea{g.dm.rows, e->row_stride, e->d_cond, e->text_emb, e->text_pos, e->speech_emb, e->speech_pos, g.h, sr.M, g.dm.out_tok};
+    HIP_TRY(launch_embed(ea, s));
+    if (e->d_dbg_emb) HIP_TRY(hipMemcpyAsync(e->d_dbg_emb, g.h, (size_t)sr.M * D * 2, hipMemcpyDeviceToDevice, s));
+    return T3_OK;
+}
+static int launch_qkv_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int L, hipStream_t s) {
+    LayerW& y = e->layers[L];
+    const int M = sr.M;
+    // 5 launches per layer: RMSNorm is folded into the qkv / gate-up GEMMs, the residual add into the o / down GEMMs
+    Prof p(e, K_QKV, s); GemmArgs a{g.h, (const uint4*)y.qkv, M, D, QKV, g.qkv, QKV, 4, 1, nullptr, 0, g.rstd};
+    HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s));
+    return T3_OK;
+}
+static int launch_attention_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int L, hipStream_t s) {
+    const int M = sr.M;
     const size_t layer_elems = (size_t)e->n_blocks * KV_BLOCK_ELEMS;
     const int max_chunks = (e->cfg.max_model_len + CHUNK - 1) / CHUNK;
-    for (int L = 0; L < e->cfg.n_layers; ++L) {
-        LayerW& y = e->layers[L];
-        uint16_t* kvL = e->kv + (size_t)L * layer_elems;
-        // 5 launches per layer: RMSNorm is folded into the qkv / gate-up GEMMs, the residual add into the o / down GEMMs
-        { Prof p(e, K_QKV, s); GemmArgs a{g.h, (const uint4*)y.qkv, M, D, QKV, g.qkv, QKV, 4, 1, nullptr, 0, g.rstd}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), s)); }
-        const int dec = sr.n_prefill_rows > 0 ? sr.decode_rows : M;      // decode rows come first in the step's row list
-        if (e->fuse_rope) {
-            // decode rows: every one is the newest position of its stream -> RoPE + KV write inside the attention kernel
-            if (dec > 0) {
-                Prof p(e, K_ATTN, s);
-                AttnArgs aa{nullptr, kvL, g.dm.rows, e->row_stride, g.att, dec, max_chunks, g.qkv, kvL, e->cos_t, e->sin_t};
-                HIP_TRY(launch_attention(aa, s));
-            }
-            // prefill rows (runs of consecutive positions): RoPE + paged KV write, then the 16-rows-per-workgroup attention
-            if (M > dec) {
-                const int* rows_p = g.dm.rows + (size_t)dec * e->row_stride;
-                { Prof p(e, K_ROPE, s); RopeArgs ra{g.qkv + (size_t)dec * QKV, g.qrot + (size_t)dec * D, kvL, rows_p, e->row_stride, e->cos_t, e->sin_t, M - dec}; HIP_TRY(launch_rope_kv(ra, s)); }
-                { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot + (size_t)dec * D, kvL, rows_p, e->row_stride, g.att + (size_t)dec * D, M - dec, max_chunks, nullptr, nullptr, nullptr, nullptr, 0, (sr.max_prefill_ctx + CHUNK - 1) / CHUNK}; HIP_TRY(launch_attention(aa, s)); }
-            }
-        } else {
-            { Prof p(e, K_ROPE, s); RopeArgs ra{g.qkv, g.qrot, kvL, g.dm.rows, e->row_stride, e->cos_t, e->sin_t, M}; HIP_TRY(launch_rope_kv(ra, s)); }
-            { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot, kvL, g.dm.rows, e->row_stride, g.att, M, max_chunks, nullptr, nullptr, nullptr, nullptr, sr.n_prefill_rows > 0 ? sr.decode_rows : -1, (sr.max_prefill_ctx + CHUNK - 1) / CHUNK}; HIP_TRY(launch_attention(aa, s)); }
+    uint16_t* kvL = e->kv + (size_t)L * layer_elems;
+    const int dec = sr.n_prefill_rows > 0 ? sr.decode_rows : M;      // decode rows come first in the step's row list
+    if (e->fuse_rope) {
+        // decode rows: every one is the newest position of its stream -> RoPE + KV write inside the attention kernel
+        if (dec > 0) {
+            Prof p(e, K_ATTN, s);
+            AttnArgs aa{nullptr, kvL, g.dm.rows, e->row_stride, g.att, dec, max_chunks, g.qkv, kvL, e->cos_t, e->sin_t};
+            HIP_TRY(launch_attention(aa, s));
         }
-        { Prof p(e, K_O, s); GemmArgs a{g.att, (const uint4*)y.o, M, D, D, g.h, D, 16, 0, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
-        { Prof p(e, K_GU, s); GemmArgs a{g.h, (const uint4*)y.gu, M, D, F, g.act, F, 4, 1, nullptr, 0, g.rstd}; HIP_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s)); }
-        { Prof p(e, K_DOWN, s); GemmArgs a{g.act, (const uint4*)y.down, M, F, D, g.h, D, 16, 0, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
+        // prefill rows (runs of consecutive positions): RoPE + paged KV write, then the 16-rows-per-workgroup attention
+        if (M > dec) {
+            const int* rows_p = g.dm.rows + (size_t)dec * e->row_stride;
+            { Prof p(e, K_ROPE, s); RopeArgs ra{g.qkv + (size_t)dec * QKV, g.qrot + (size_t)dec * D, kvL, rows_p, e->row_stride, e->cos_t, e->sin_t, M - dec}; HIP_TRY(launch_rope_kv(ra, s)); }
+            { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot + (size_t)dec * D, kvL, rows_p, e->row_stride, g.att + (size_t)dec * D, M - dec, max_chunks, nullptr, nullptr, nullptr, nullptr, 0, (sr.max_prefill_ctx + CHUNK - 1) / CHUNK}; HIP_TRY(launch_attention(aa, s)); }
+        }
+    } else {
+        { Prof p(e, K_ROPE, s); RopeArgs ra{g.qkv, g.qrot, kvL, g.dm.rows, e->row_stride, e->cos_t, e->sin_t, M}; HIP_TRY(launch_rope_kv(ra, s)); }
+        { Prof p(e, K_ATTN, s); AttnArgs aa{g.qrot, kvL, g.dm.rows, e->row_stride, g.att, M, max_chunks, nullptr, nullptr, nullptr, nullptr, sr.n_prefill_rows > 0 ? sr.decode_rows : -1, (sr.max_prefill_ctx + CHUNK - 1) / CHUNK}; HIP_TRY(launch_attention(aa, s)); }
     }
-    if (n_sel > 0) {
-        // final RMSNorm folded into the speech-head GEMM, which gathers the sampled rows itself
-        { Prof p(e, K_HEAD, s); GemmArgs a{g.h, (const uint4*)e->head, 2 * n_sel, D, V, g.logits, VPAD, 4, 1, g.dm.sel_rows, HEAD_TILES}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16, 4, true), s)); }
-        { Prof p(e, K_SAMPLE, s); SampleArgs sa{g.logits, VPAD, g.dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, g.dm.out_tok, e->d_dbg, n_sel, e->d_hist, e->cfg.max_model_len}; HIP_TRY(launch_sampler(sa, s)); }
+    return T3_OK;
+}
+static int launch_mlp_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int L, hipStream_t s) {
+    LayerW& y = e->layers[L];
+    const int M = sr.M;
+    { Prof p(e, K_O, s); GemmArgs a{g.att, (const uint4*)y.o, M, D, D, g.h, D, 16, 0, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
+    { Prof p(e, K_GU, s); GemmArgs a{g.h, (const uint4*)y.gu, M, D, F, g.act, F, 4, 1, nullptr, 0, g.rstd}; HIP_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s)); }
+    { Prof p(e, K_DOWN, s); GemmArgs a{g.act, (const uint4*)y.down, M, F, D, g.h, D, 16, 0, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
+    return T3_OK;
+}
+static int launch_sample_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, hipStream_t s) {
+    const int n_sel = sr.n_sel;
+    if (n_sel <= 0) return T3_OK;
+    // final RMSNorm folded into the speech-head GEMM, which gathers the sampled rows itself
+    { Prof p(e, K_HEAD, s); GemmArgs a{g.h, (const uint4*)e->head, 2 * n_sel, D, V, g.logits, VPAD, 4, 1, g.dm.sel_rows, HEAD_TILES}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16, 4, true), s)); }
+    { Prof p(e, K_SAMPLE, s); SampleArgs sa{g.logits, VPAD, g.dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, g.dm.out_tok, e->d_dbg, n_sel, e->d_hist, e->cfg.max_model_len}; HIP_TRY(launch_sampler(sa, s)); }
+    return T3_OK;
+}
+static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, hipStream_t s) {
+    int rc;
+    if ((rc = launch_embed_phase(e, g, sr, s))) return rc;
+    for (int L = 0; L < e->cfg.n_layers; ++L) {
+        if ((rc = launch_qkv_phase(e, g, sr, L, s))) return rc;
+        if ((rc = launch_attention_phase(e, g, sr, L, s))) return rc;
+        if ((rc = launch_mlp_phase(e, g, sr, L, s))) return rc;
     }
+    return launch_sample_phase(e, g, sr, s);
+}
+// The two-track schedule of a decode-only step (T3Engine::antiphase): track 0 on `s0`, track 1 on the side stream, forked from and
+// joined back into s0; the attention launches pass a token A(0) -> B(0) -> A(1) -> B(1) ... so that at any time at most one track
+// is in its HBM-bound phase and the other one's GEMM chain (a few MB per launch, latency-bound) runs beside it.
+static int launch_step_two_tracks(T3Engine* e, const T3Engine::Step& st, hipStream_t s0) {
+    hipStream_t ss[2] = {s0, e->side_stream};
+    int rc;
+    HIP_TRY(hipEventRecord(e->ev_fork, s0));
+    HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+    for (int t = 0; t < 2; ++t) if ((rc = launch_embed_phase(e, e->groups[t], st.g[t], ss[t]))) return rc;
+    for (int L = 0; L < e->cfg.n_layers; ++L)
+        for (int t = 0; t < 2; ++t) {
+            if ((rc = launch_qkv_phase(e, e->groups[t], st.g[t], L, ss[t]))) return rc;
+            if (L > 0 || t > 0) HIP_TRY(hipStreamWaitEvent(ss[t], t == 0 ? e->ev_att[2 * (L - 1) + 1] : e->ev_att[2 * L], 0));
+            if ((rc = launch_attention_phase(e, e->groups[t], st.g[t], L, ss[t]))) return rc;
+            HIP_TRY(hipEventRecord(e->ev_att[2 * L + t], ss[t]));
+            if ((rc = launch_mlp_phase(e, e->groups[t], st.g[t], L, ss[t]))) return rc;
+        }
+    for (int t = 0; t < 2; ++t) if ((rc = launch_sample_phase(e, e->groups[t], st.g[t], ss[t]))) return rc;
+    HIP_TRY(hipEventRecord(e->ev_join, e->side_stream));
+    HIP_TRY(hipStreamWaitEvent(s0, e->ev_join, 0));
     return T3_OK;
 }
 
@@ -635,45 +702,84 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
     st.t_begin = std::chrono::steady_clock::now();
     if (st.M_all == 0) return T3_OK;
 
+    // antiphase engines order every step on groups[0].stream (the second track is a branch inside the step)
+    auto stream_of = [&](int gi) { return e->antiphase ? e->groups[0].stream : e->groups[gi].stream; };
+    const bool graphs_ok = !e->cfg.enforce_eager && !e->profile && st.n_prefill_rows == 0;
+    const bool two_tracks = e->antiphase && st.n_prefill_rows == 0 && st.g[0].M > 0 && st.g[1].M > 0;
     for (int gi = 0; gi < e->n_groups; ++gi) {
         T3Engine::Group& g = e->groups[gi];
         const T3Engine::StepRec& sr = st.g[gi];
         if (sr.M == 0) continue;
-        HIP_TRY(hipStreamWaitEvent(g.stream, e->ev_admit, 0));
-        HIP_TRY(hipMemcpyAsync(g.d_meta, g.h_meta[buf], g.meta_rows_off + (size_t)sr.M * e->row_stride * 4, hipMemcpyHostToDevice, g.stream));   // sel arrays + the used row records
+        hipStream_t s = stream_of(gi);
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_admit, 0));
+        HIP_TRY(hipMemcpyAsync(g.d_meta, g.h_meta[buf], g.meta_rows_off + (size_t)sr.M * e->row_stride * 4, hipMemcpyHostToDevice, s));   // sel arrays + the used row records
         if (e->d_dbg_emb) {
             e->dbg_emb_rec.resize((size_t)2 * sr.M);
             for (int r = 0; r < sr.M; ++r) { const int* rec = g.hm[buf].rows + (size_t)r * e->row_stride; e->dbg_emb_rec[2 * r] = rec[0]; e->dbg_emb_rec[2 * r + 1] = rec[1]; }
         }
-        const bool use_graph = !e->cfg.enforce_eager && !e->profile && sr.n_prefill_rows == 0;
-        if (use_graph) {
+        if (two_tracks) continue;                        // launched below, both tracks in one go
+        if (graphs_ok) {
             const auto key = std::make_pair(sr.M, sr.n_sel);
             auto it = g.graphs.find(key);
             if (it == g.graphs.end()) {
                 hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
                 const auto tc0 = std::chrono::steady_clock::now();
-                HIP_TRY(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
-                const int lrc = launch_step(e, g, sr);
-                const hipError_t ce = hipStreamEndCapture(g.stream, &graph);
+                HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                const int lrc = launch_step(e, g, sr, s);
+                const hipError_t ce = hipStreamEndCapture(s, &graph);
                 if (lrc) return lrc;
                 HIP_TRY(ce);
                 HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
                 (void)hipGraphDestroy(graph);
                 if (g.graphs.size() > 64) {          // a replay of one of them may still be running (run-ahead): drain first
-                    HIP_TRY(hipStreamSynchronize(g.stream));
+                    HIP_TRY(hipStreamSynchronize(s));
                     for (auto& kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
                     g.graphs.clear();
                 }
                 it = g.graphs.emplace(key, exec).first;
                 ++e->graph_captures; e->graph_capture_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
             }
-            HIP_TRY(hipGraphLaunch(it->second, g.stream));
+            HIP_TRY(hipGraphLaunch(it->second, s));
         } else {
             int lrc;
-            if ((lrc = launch_step(e, g, sr))) return lrc;
+            if ((lrc = launch_step(e, g, sr, s))) return lrc;
         }
-        if (sr.n_sel > 0) HIP_TRY(hipMemcpyAsync(g.h_out_tok[buf], g.dm.out_tok, (size_t)sr.n_sel * 4, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipEventRecord(g.ev_done[buf], g.stream));
+        if (sr.n_sel > 0) HIP_TRY(hipMemcpyAsync(g.h_out_tok[buf], g.dm.out_tok, (size_t)sr.n_sel * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(g.ev_done[buf], s));
+    }
+    if (two_tracks) {
+        hipStream_t s = e->groups[0].stream;
+        if (graphs_ok) {
+            const std::array<int, 4> key{st.g[0].M, st.g[0].n_sel, st.g[1].M, st.g[1].n_sel};
+            auto it = e->graphs2.find(key);
+            if (it == e->graphs2.end()) {
+                hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+                const auto tc0 = std::chrono::steady_clock::now();
+                HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                const int lrc = launch_step_two_tracks(e, st, s);
+                const hipError_t ce = hipStreamEndCapture(s, &graph);
+                if (lrc) return lrc;
+                HIP_TRY(ce);
+                HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                if (e->graphs2.size() > 64) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    for (auto& kv : e->graphs2) (void)hipGraphExecDestroy(kv.second);
+                    e->graphs2.clear();
+                }
+                it = e->graphs2.emplace(key, exec).first;
+                ++e->graph_captures; e->graph_capture_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
+            }
+            HIP_TRY(hipGraphLaunch(it->second, s));
+        } else {
+            int lrc;
+            if ((lrc = launch_step_two_tracks(e, st, s))) return lrc;
+        }
+        for (int gi = 0; gi < 2; ++gi) {
+            T3Engine::Group& g = e->groups[gi];
+            if (st.g[gi].n_sel > 0) HIP_TRY(hipMemcpyAsync(g.h_out_tok[buf], g.dm.out_tok, (size_t)st.g[gi].n_sel * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(g.ev_done[buf], s));
+        }
     }
     return T3_OK;
 }
@@ -743,7 +849,7 @@ static int complete_step(T3Engine* e, T3Engine::Step& st, T3StepResult* res) {
                     }
                     if (!e->out_pool.empty()) {
                         r.d_out = e->out_pool.back(); e->out_pool.pop_back();
-                        const hipError_t ce = hipMemcpyAsync(r.d_out, e->d_hist + (size_t)r.slot * e->cfg.max_model_len, r.out.size() * 4, hipMemcpyDeviceToDevice, e->groups[gi].stream);
+                        const hipError_t ce = hipMemcpyAsync(r.d_out, e->d_hist + (size_t)r.slot * e->cfg.max_model_len, r.out.size() * 4, hipMemcpyDeviceToDevice, e->antiphase ? e->groups[0].stream : e->groups[gi].stream);
                         if (ce != hipSuccess && !dev_rc) dev_rc = e->fail(T3_E_DEVICE, std::string("hand-off copy of a finished utterance's ids failed: ") + hipGetErrorString(ce));
                     }
                 }

@@ -44,8 +44,13 @@ namespace t3 {
 #ifdef T3_GEMM_CLK      // diagnostic build only (tools/gemm_clk.hip): per-workgroup phase stamps, 100 MHz ticks
 __device__ unsigned long long g_gemm_clk[8][2048][5];
 #define T3_GSTAMP(i) do { if (threadIdx.x == 0) g_gemm_clk[(EPI * 2 + (NW == 16)) & 7][(blockIdx.y * gridDim.x + blockIdx.x) & 2047][i] = wall_clock64(); } while (0)
+// gemm2_kernel (the current decode schedule): class 0 qkv / head, 1 gate/up, 2 o, 3 down; stamps: 0 entry, 1 A rows landed and staged
+// in LDS, 2 first weight k-block landed, 3 last MFMA issued, 4 partials exchanged (barrier passed), 5 outputs stored
+__device__ unsigned long long g_gemm2_clk[4][2048][6];
+#define T3_G2STAMP(i) do { if (threadIdx.x == 0) g_gemm2_clk[NORM ? (EPI == EPI_SILU ? 1 : 0) : (KBS == 2 ? 2 : 3)][(blockIdx.y * gridDim.x + blockIdx.x) & 2047][i] = wall_clock64(); } while (0)
 #else
 #define T3_GSTAMP(i)
+#define T3_G2STAMP(i)
 #endif
 template <int MT, int NT, int EPI, int PD, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmArgs a) {
@@ -205,6 +210,7 @@ __device__ __forceinline__ unsigned a_img_off(int row, int ch) {     // byte off
 
 template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
 __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
+    T3_G2STAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];      // [NW waves][MT][16 rows][KBS * 64 B] | NORM: float [NW][MT*16]
     static_assert(NT <= KBS && (KBS == 8 || KBS == 2) && (NW == 4 || NW == 16), "gemm2 shapes");
     constexpr int LPR = KBS * 4, RPI = 64 / LPR;                // lanes (= 16-byte chunks) per row slice, rows per wave instruction
@@ -263,6 +269,7 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
         for (int t = 0; t < KBS; ++t)
             *reinterpret_cast<uint4_v*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(t * RPI + rsub, ch)) = ar[i][t];
     asm volatile("" ::: "memory");
+    T3_G2STAMP(1);
     f32x4 acc[MT][NT], ss[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -278,6 +285,7 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
         wait_vmcnt<(KBS - 1 - kb) * NT>();            // this k-block's NT weight tiles have landed ((KBS - 1 - kb) * NT younger loads may still fly)
 #pragma unroll
         for (int t = 0; t < NT; ++t) landed(wr[kb][t]);
+        if constexpr (kb == 0) T3_G2STAMP(2);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             if constexpr (NORM) ss[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(af[i]), ss[i], 0, 0, 0);   // diagonal = sum of squares
@@ -286,6 +294,7 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
                 acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][t]), acc[i][t], 0, 0, 0);
         }
     }, std::make_integer_sequence<int, KBS>{});
+    T3_G2STAMP(3);
     // ---- partials over the wave's own (now dead) A image: [tile][r][lane]
     asm volatile("" ::: "memory");
     float* redw = reinterpret_cast<float*>(aimg);
@@ -305,6 +314,7 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
         }
     }
     __syncthreads();
+    T3_G2STAMP(4);
     auto part = [&](int w) { return reinterpret_cast<const float*>(lds2 + (size_t)w * ABYTES); };
 
     if constexpr (NW == 4) {
@@ -376,6 +386,7 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
             }
         }
     }
+    T3_G2STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1268,14 +1279,39 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
     constexpr int CPB = KV_BLOCK / CHUNK;          // chunks per physical block
 
     uint4 kf[8], vf[8];                            // K fragments (tt, ds) at 2 tt + ds; V fragments (dt, ts) at 2 dt + ts
+    // A chunk's tile is 8 K fragments (16 tokens x 32 dims each) + 8 V fragments (32 tokens x 16 dims each).  Of the context's LAST
+    // chunk only the fragments that hold tokens of the pool are requested (the fused form's newest token comes from registers): on
+    // average a third of that tile, ~4 % of a launch's bytes at C3.  Fragments left out are zeroed: their scores are masked anyway, but
+    // a V fragment meets p = 0 in the MFMA and 0 x (a stale NaN pattern) would not be 0.
+#ifdef T3_ATTN_FULL_TILES
+    constexpr bool PARTIAL = false;
+#else
+    constexpr bool PARTIAL = true;
+#endif
     auto load_tiles = [&](int c) {
         const int blk = bt[c / CPB], ci = c % CPB;
         const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 0, h) + (size_t)ci * (CHUNK * HD)) + lane;
         const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 1, h) + (size_t)ci * (CHUNK * HD)) + lane;
+        const int npool = L - (FUSE ? 1 : 0) - c * CHUNK;       // tokens of this chunk that live in the pool (wave-uniform; >= 64 except in the last chunk)
+        if (!PARTIAL || npool >= CHUNK) {
 #pragma unroll
-        for (int f = 0; f < 8; ++f) kf[f] = NT ? ld_nt(Kp + f * 64) : Kp[f * 64];
+            for (int f = 0; f < 8; ++f) kf[f] = NT ? ld_nt(Kp + f * 64) : Kp[f * 64];
 #pragma unroll
-        for (int f = 0; f < 8; ++f) vf[f] = NT ? ld_nt(Vp + f * 64) : Vp[f * 64];
+            for (int f = 0; f < 8; ++f) vf[f] = NT ? ld_nt(Vp + f * 64) : Vp[f * 64];
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                if (16 * tt < npool) { kf[2 * tt] = NT ? ld_nt(Kp + (2 * tt) * 64) : Kp[(2 * tt) * 64]; kf[2 * tt + 1] = NT ? ld_nt(Kp + (2 * tt + 1) * 64) : Kp[(2 * tt + 1) * 64]; }
+                else { kf[2 * tt] = make_uint4(0, 0, 0, 0); kf[2 * tt + 1] = make_uint4(0, 0, 0, 0); }
+            }
+#pragma unroll
+            for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    if (32 * ts < npool) vf[2 * dt + ts] = NT ? ld_nt(Vp + (2 * dt + ts) * 64) : Vp[(2 * dt + ts) * 64];
+                    else vf[2 * dt + ts] = make_uint4(0, 0, 0, 0);
+                }
+        }
     };
 
     // the wave's first K/V tile is requested before anything else so that the q / RoPE prologue overlaps its flight

@@ -96,7 +96,7 @@ class LLM:
                  enforce_eager: bool = True, max_model_len: int = 1000, max_num_seqs: int = 256,
                  max_num_batched_tokens: int = 0, seed: int = 0, load_format: str = "auto", dtype: str = "bfloat16",
                  device_id: Optional[int] = None, tokenizer_file: Optional[str] = None, num_hidden_layers: Optional[int] = None,
-                 kv_cache_bytes: int = 0, debug_logits: bool = False, **kwargs):
+                 kv_cache_bytes: int = 0, debug_logits: bool = False, honor_enforce_eager: Optional[bool] = None, **kwargs):
         if task != "generate":
             raise ValueError("only task='generate' exists on the T3 path")
         if dtype not in ("bfloat16", "auto", torch.bfloat16):
@@ -114,9 +114,14 @@ class LLM:
             torch.cuda.set_device(device_id)      # torch-side work of this process (RCCL collectives of dp.py, hand-off tensors) runs on the engine's GPU
         # enforce_eager: in vLLM it switches off CUDA-graph capture and torch.compile (start-up time and memory knobs; the
         # reference server always passes True, api_server.py:157 -> tts.py:156,163).  Here a decode step is replayed from a
-        # hipGraph captured on first use -- no compile step, a few MB -- and token ids do not depend on it, so the flag is
-        # accepted and NOT applied unless T3_HONOR_ENFORCE_EAGER=1 asks for launch-by-launch steps (debugging, profiling).
-        eager = bool(enforce_eager) and os.environ.get("T3_HONOR_ENFORCE_EAGER", "0") == "1"
+        # hipGraph captured on first use -- no compile step, a few MB -- and token ids do not depend on it, so by default the
+        # flag is accepted and NOT applied.  `honor_enforce_eager=True` (a kwarg of this class, forwarded by tts.py:171's **kwargs;
+        # default: the T3_HONOR_ENFORCE_EAGER environment variable, else False) makes enforce_eager=True mean launch-by-launch
+        # steps, as in vLLM (debugging, profiling: +43 % step time at B = 1).
+        if honor_enforce_eager is None:
+            honor_enforce_eager = os.environ.get("T3_HONOR_ENFORCE_EAGER", "0") == "1"
+        self.honor_enforce_eager = bool(honor_enforce_eager)
+        eager = bool(enforce_eager) and self.honor_enforce_eager
         self.engine = T3Engine(n_layers=n_layers, text_vocab=text_vocab, max_model_len=max_model_len, max_seqs=max_num_seqs,
                                device_id=device_id, kv_bytes=kv_cache_bytes, gpu_memory_utilization=gpu_memory_utilization,
                                enforce_eager=eager, debug_logits=debug_logits, max_batched_rows=max_num_batched_tokens)

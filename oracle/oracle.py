@@ -81,6 +81,7 @@ def lib():
         L.orc_philox.argtypes = [ct.c_uint32] * 6 + [vp]
         L.orc_sample.restype = i32; L.orc_sample.argtypes = [vp, vp, ct.POINTER(Sampling), ct.c_uint32]
         L.orc_prompt_embeds.restype = i32; L.orc_prompt_embeds.argtypes = [vp, vp, i32, vp, vp, vp]
+        L.orc_decode_embed.restype = i32; L.orc_decode_embed.argtypes = [vp, i32, i32, vp]
         L.orc_generate.restype = i32
         L.orc_generate.argtypes = [vp, i32, vp, i32, vp, ct.POINTER(Sampling), f32, i32, vp, vp]
         L.orc_decode_steps_timing.argtypes = [vp, i32, i32, i32]
@@ -248,6 +249,13 @@ class OracleModel:
         if rc:
             raise ValueError(f"orc_prompt_embeds failed: {rc}")
         return ec, eu
+
+    def decode_embed(self, tok: int, k: int) -> torch.Tensor:
+        """speech_emb[tok] + speech_pos_emb[k] as a bf16 row (both CFG halves get the same row, t3.py:480)"""
+        out = torch.empty(D, dtype=torch.bfloat16)
+        if lib().orc_decode_embed(self.h, int(tok), int(k), _p(out)):
+            raise ValueError("decode_embed: token or position out of range")
+        return out
 
     def forward_rows(self, h: torch.Tensor, row_stream, row_pos, tap_layer: int = -1):
         """Runs all layers in place on a copy of h ([rows,1024] bf16); returns (h_out, tap)."""

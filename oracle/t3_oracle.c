@@ -667,6 +667,17 @@ int orc_prompt_embeds(OrcModel* m, const int32_t* prompt_ids, int T, const float
     return 0;
 }
 
+/* ------------------------------------------------------------------ decode embedding  (t3.py:440-486)
+ * The row fed back for a generated speech token: speech_emb[tok] + speech_pos_emb[k], the same for the conditional and the
+ * unconditional half (t3.py:480).  k = number of tokens generated so far (pos_policy 0, SURVEY.md 9 Q1 "exact") or 0 (pos_policy 1:
+ * what row [0, 0, :] of the reference's decode branch holds for a single token; tests/golden/prompt_embeds.npz records both). */
+int orc_decode_embed(OrcModel* m, int tok, int k, uint16_t* out /* [1024] */) {
+    if (tok < 0 || tok >= T3_V || k < 0 || k >= T3_SPEECH_POS) return -1;
+    for (int d = 0; d < T3_D; ++d)
+        out[d] = f2bf(bf2f(m->speech_emb[(size_t)tok * T3_D + d]) + bf2f(m->speech_pos[(size_t)k * T3_D + d]));
+    return 0;
+}
+
 /* ------------------------------------------------------------------ end-to-end generate (one utterance)
  * Uses streams 2*slot (cond) and 2*slot+1 (uncond) of the oracle's KV cache.
  * out_ids: speech-space ids (NOT offset by 2500).  logits_out (optional): [n][8194] post-CFG logits
@@ -697,8 +708,8 @@ int orc_generate(OrcModel* m, int slot, const int32_t* prompt_ids, int T, const 
         if (n >= limit) break;
         /* decode embedding: speech_emb[tok] + speech_pos[k], k = n (exact) or 0 (literal) -- t3.py:440-480 */
         const int k = (sp->pos_policy == 0) ? (n % T3_SPEECH_POS) : 0;
-        for (int d = 0; d < T3_D; ++d)
-            h2[d] = h2[T3_D + d] = f2bf(bf2f(m->speech_emb[(size_t)tok * T3_D + d]) + bf2f(m->speech_pos[(size_t)k * T3_D + d]));
+        orc_decode_embed(m, tok, k, h2);
+        memcpy(h2 + T3_D, h2, T3_D * 2);
         int s2[2] = {2 * slot, 2 * slot + 1}, p2[2] = {T - 1 + n, T - 1 + n};
         orc_forward_rows(m, h2, s2, p2, 2, -1, NULL);
         memcpy(hc, h2, T3_D * 2); memcpy(hu, h2 + T3_D, T3_D * 2);

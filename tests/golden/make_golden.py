@@ -12,6 +12,9 @@ What comes from where:
                           branch literally returns; t3.py imported with raise-on-use placeholders for the vllm names it imports.
   G3  rope.npz         -- inv_freq and cos/sin of transformers' LlamaRotaryEmbedding for the reference's
                           t3-model/config.json rope settings.
+  G4  hf_gate.npz      -- transformers LlamaModel (fp32 and bf16) on the gate's weights: HF-fp32 CFG logits and hidden states after
+                          1 / 2 / 30 layers at three steps, plus 128 steps of per-step error / agreement / nucleus-overlap figures
+                          of the oracle and of HF-bf16 against HF-fp32 (tests/hf_gate.py).
   G5/G6 streams.npz    -- oracle token streams + post-CFG logits on seeded synthetic weights
                           (2-layer English, 2-layer multilingual batch, 30-layer short) -- regression
                           pins for both the oracle and the GPU engine.
@@ -483,6 +486,61 @@ def g2_prompt_embeds():
     np.savez_compressed(os.path.join(HERE, "prompt_embeds.npz"), **out)
     print("G2 prompt_embeds:", {k: (v.shape if v.ndim else v.item()) for k, v in out.items() if "crc" not in k})
 
+def g4_hf_gate():
+    """hf_gate.npz -- the fidelity gate of tests/hf_gate.py at FULL length (128 teacher-forced decode steps, two
+    prompts: 22 text ids / English vocabulary, and the 141-row es prompt of C3 / multilingual vocabulary), 30 layers, non-trivial norm
+    weights, against transformers' LlamaModel in fp32 AND in bf16:
+      * committed HF vectors, so that the pin does not depend on `transformers` at test time: HF-fp32 post-CFG logits [8194] and hidden
+        states after 1 / 2 / 30 layers (both CFG streams) at steps 0, 1, 2 (prefill's last row, then two KV-cache decode steps);
+      * the per-step evidence over all 128 steps: max / mean logit error of the oracle and of HF-bf16 against HF-fp32, greedy agreement
+        and HF's top-1 / top-2 margin, overlap of the top-p = 0.8 nuclei."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hf_gate as H
+    from oracle import oracle as O
+    from util import make_prompt
+    from chatterbox_vllm2_amd.prompt import assemble_prompt_ids
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb
+    tok = json.load(open(os.path.join(HERE, "tokenizer.json")))
+    cond = synthetic_cond_emb(1)
+    NL, N, SEL = 30, 128, (0, 1, 2)
+    out = {"sel_steps": np.array(SEL, np.int32), "n_steps": np.int32(N)}
+    for name, vocab, prompt in (("p22", 704, make_prompt(22, seed=5)), ("es", 2454, assemble_prompt_ids(tok["es_mtl_ids"]))):
+        import time
+        t0 = time.time()
+        tens = H.gate_tensors(NL, vocab)
+        ids, lg, fin, _ = H.oracle_teacher_forced(O, tens, NL, vocab, prompt, cond, N)
+        m = O.OracleModel(NL, vocab, max_pos=len(prompt) + 4).load(tens)
+        ec, eu = m.prompt_embeds(prompt, cond)
+        gen_ids, _ = m.generate(prompt, cond, O.make_sampling(temperature=0.0, repetition_penalty=1.0, max_tokens=3, ignore_eos=True), max_model_len=len(prompt) + 4)
+        m.close()
+        assert gen_ids == ids[:3]                                  # the row-by-row drive is the generate loop
+        t1 = time.time()
+        lg32, hid32, tap32 = H.hf_teacher_forced(tens, NL, ec, eu, ids, torch.float32, taps=(1, 2))
+        t2 = time.time()
+        lg16, hid16, tap16 = H.hf_teacher_forced(tens, NL, ec, eu, ids, torch.bfloat16, taps=(1, 2))
+        t3 = time.time()
+        cmp = H.compare(lg, lg32, lg16, ids)
+        # the oracle's own taps at the committed steps (for the record: error of the hidden states against HF fp32, oracle vs HF bf16)
+        ids3, _, fin3, otap = H.oracle_teacher_forced(O, tens, NL, vocab, prompt, cond, len(SEL), taps=(1, 2))
+        nw = dict(tens)["tfmr.norm.weight"].float()
+        f32 = fin3.float(); post = f32 * torch.rsqrt(f32.pow(2).mean(-1, keepdim=True) + 1e-5) * nw
+        sel = list(SEL)
+        out[f"{name}_ids"] = np.array(ids, np.int16)
+        out[f"{name}_prompt"] = np.array(prompt, np.int32)
+        out[f"{name}_hf32_logits"] = lg32[sel].numpy()
+        out[f"{name}_hf32_hidden_l1"] = tap32[1][sel].numpy(); out[f"{name}_hf32_hidden_l2"] = tap32[2][sel].numpy()
+        out[f"{name}_hf32_hidden_l30_postnorm"] = hid32[sel].numpy()
+        out[f"{name}_hidden_err_oracle"] = np.array([(otap[1].float() - tap32[1][sel]).abs().mean(), (otap[2].float() - tap32[2][sel]).abs().mean(), (post - hid32[sel]).abs().mean()])
+        out[f"{name}_hidden_err_hfbf16"] = np.array([(tap16[1][sel] - tap32[1][sel]).abs().mean(), (tap16[2][sel] - tap32[2][sel]).abs().mean(), (hid16[sel] - hid32[sel]).abs().mean()])
+        for k, v in cmp.items():
+            out[f"{name}_{k}"] = np.asarray(v)
+        print(f"  {name}: T = {len(prompt)}, oracle {t1 - t0:.0f} s, HF fp32 {t2 - t1:.0f} s, HF bf16 {t3 - t2:.0f} s; max logit err oracle {cmp['err_max_oracle'].max():.4f} "
+              f"/ HF-bf16 {cmp['err_max_hfbf16'].max():.4f}; mean err ratio oracle / HF-bf16 max over steps {np.max(cmp['err_mean_oracle'] / cmp['err_mean_hfbf16']):.3f}; "
+              f"greedy agreement {int(cmp['agree_oracle'].sum())}/{N}; nucleus Jaccard min oracle {cmp['nucleus_jaccard_oracle'].min():.4f} / HF-bf16 {cmp['nucleus_jaccard_hfbf16'].min():.4f}; "
+              f"hidden err oracle {out[name + '_hidden_err_oracle']} HF-bf16 {out[name + '_hidden_err_hfbf16']}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "hf_gate.npz"), **out)
+    print("G4 hf_gate:", {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim})
+
 
 def g8_postfilter():
     """Decisions of the reference's AlignmentStreamAnalyzer (imported; run on CPU) driven by the loop of tts.py:329-350."""
@@ -532,4 +590,5 @@ if __name__ == "__main__":
     if "g9" in which: g9_c4_requests()
     if "g6b" in which: g6b_streams_30_layers_multilingual()
     if "g2" in which: g2_prompt_embeds()
+    if "g4" in which: g4_hf_gate()                         # not in the default list: ~10 minutes of CPU
     if "g6c" in which: g6c_full_length_streams()          # not in the default list: about an hour of CPU

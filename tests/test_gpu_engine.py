@@ -296,7 +296,14 @@ def test_llm_surface(E, oracle, tiny_oracle, cond, tmp_path):
     assert st.kv_blocks_free == st.kv_blocks_total
     nxt = llm.generate([good], SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True))       # the engine is still usable and empty
     assert len(nxt[0].outputs[0].token_ids) == 8
+    assert llm.engine.cfg.enforce_eager == 0                  # enforce_eager=True is accepted and not applied by default ...
     llm.shutdown()
+    eager = LLM(model="./t3-model", tokenizer="EnTokenizer", enforce_eager=True, honor_enforce_eager=True, max_model_len=400, max_num_seqs=4,
+                load_format="dummy", num_hidden_layers=2, kv_cache_bytes=1 << 28)
+    assert eager.engine.cfg.enforce_eager == 1                # ... unless the caller asks for vLLM's meaning: launch by launch, same ids
+    r2 = eager.generate([c1], SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=64, ignore_eos=True))
+    assert [t - 2500 for t in r2[0].outputs[0].token_ids] == z["l2_en_greedy_ids"].tolist()
+    eager.shutdown()
 
 
 def test_abort_request_states(E, tiny_engine, cond):

@@ -72,21 +72,26 @@ def test_c2_full_depth_30_layers(ctx):
 
 
 def test_full_size_batch_invariance_c3(ctx):
-    """BASELINE size (30 layers, B = 32, max_model_len 1000, graph replay): utterances 0 (en) and 17 (es) of the batch against their
-    committed 30-layer ORACLE streams (streams30.npz) -- the 64-row production GEMM schedules at full depth -- and an utterance's
-    stream does not depend on its batch (B = 32 vs B = 1)."""
+    """BASELINE size (30 layers, B = 32, max_model_len 1000, graph replay), every utterance run to the END of its length (884 / 859
+    tokens, contexts up to 1000): utterances 0 (en) and 17 (es) of the batch against their committed FULL-LENGTH 30-layer ORACLE
+    streams (streams30_full.npz, make_golden.py g6c) -- the 64-row production schedules and the 4-wave fused attention at every
+    context the bench times them at -- and an utterance's stream does not depend on its batch (B = 32 vs B = 1)."""
     E = ctx["E"]
     en, es = ctx["asm"](ctx["tok"]["en_mtl_ids"]), ctx["asm"](ctx["tok"]["es_mtl_ids"])
     eng = E.T3Engine(n_layers=30, text_vocab=2454, max_model_len=1000, max_seqs=32, kv_bytes=10 << 30, enforce_eager=False, max_batched_rows=8192)
     eng.load_tensors(ctx["syn"](30, 2454, 1234)); eng.finalize()
-    kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, max_tokens=24, ignore_eos=True)
+    kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, max_tokens=1000, ignore_eos=True)
     for i in range(32):
         eng.add_request(i, en if i < 16 else es, ctx["cond"], E.make_sampling(uid=i, **kw))
     eng.run_until_done()
     batch = {i: eng.get_output(i)[0] for i in range(32)}
-    z30 = np.load(os.path.join(G, "streams30.npz"))
+    zf = np.load(os.path.join(G, "streams30_full.npz")); z30 = np.load(os.path.join(G, "streams30.npz"))
     for i in (0, 17):
-        assert [t - 2500 for t in batch[i]] == z30[f"c3_uid{i}_ids"].tolist(), f"utterance {i} of the B=32 batch differs from the 30-layer oracle stream"
+        want = zf[f"c3_uid{i}_ids"].tolist()
+        assert len(want) == 1000 - (116 if i < 16 else 141) and want[:24] == z30[f"c3_uid{i}_ids"].tolist()
+        got = [t - 2500 for t in batch[i]]
+        first = next((k for k, (a, b) in enumerate(zip(got, want)) if a != b), None)
+        assert got == want, f"utterance {i} of the B=32 batch leaves the full-length 30-layer oracle stream at token {first} of {len(want)}"
     for i in range(32):
         eng.release(i)
     for i in (0, 17, 31):
@@ -117,7 +122,8 @@ def test_c4_continuous_batching_full_size(ctx):
     st = eng.stats()
     assert st.tokens_generated == sum(r["max_tokens"] for r in reqs)
     assert st.kv_blocks_free == total_blocks == st.kv_blocks_total
-    checked = 0
+    zf = np.load(os.path.join(G, "streams30_full.npz"))
+    checked = full = 0
     for i, r in enumerate(reqs):
         ids, fr = eng.get_output(i)
         assert len(ids) == r["max_tokens"] and fr == 2
@@ -126,8 +132,12 @@ def test_c4_continuous_batching_full_size(ctx):
             want = z30[key].tolist()
             assert [t - 2500 for t in ids[:len(want)]] == want, f"C4 request {i} ({r['lang']}) differs from the 30-layer oracle stream"
             checked += 1
+        if key in zf.files:                              # two requests (fr, 317 tokens; zh, 767 tokens) to their full max_tokens
+            want = zf[key].tolist()
+            assert len(want) == r["max_tokens"] and [t - 2500 for t in ids] == want, f"C4 request {i} ({r['lang']}) leaves its full-length oracle stream"
+            full += 1
         eng.release(i)
-    assert checked == 6
+    assert checked == 6 and full == 2
     eng.close()
 
 
@@ -144,6 +154,7 @@ def test_c2_b1_through_llm_as_the_server_drives_it(ctx):
     r = llm.generate([{"prompt_token_ids": p, "multi_modal_data": {"conditionals": [ctx["cond"]]}}],
                      SamplingParams(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, max_tokens=400 - 108, ignore_eos=True))
     ids = [t - 2500 for t in r[0].outputs[0].token_ids]
-    want = ctx["z"]["l30_en_sampled_ids"].tolist()
-    assert len(ids) == 292 and ids[:len(want)] == want and r[0].outputs[0].finish_reason == "length"
+    want = np.load(os.path.join(G, "streams30_full.npz"))["c2_en_sampled_ids"].tolist()
+    assert len(want) == 292 and want[:16] == ctx["z"]["l30_en_sampled_ids"].tolist()
+    assert ids == want and r[0].outputs[0].finish_reason == "length"
     llm.shutdown()

@@ -68,6 +68,55 @@ def test_prompt_embeds_layout(oracle, tiny_weights):
         m.prompt_embeds(prompt[:20], cond)
 
 
+def _crc_rows(t):
+    import zlib
+    b = t.contiguous().view(torch.int16).numpy()
+    return np.array([zlib.crc32(b[i].tobytes()) for i in range(b.shape[0])], dtype=np.uint32)
+
+
+def test_prompt_and_decode_embeddings_vs_reference_code(oracle):
+    """a5 / a9 / a10 / a11 against OUTPUTS OF THE REFERENCE'S OWN CODE (tests/golden/prompt_embeds.npz: models/t3/t3.py imported in the
+    build container, make_golden.py g2): the oracle's prompt embeddings equal T3VllmModel.get_input_embeddings bit for bit -- the full
+    block for the three BASELINE prompts (t3.py:542-561), every two-chunk split of a short prompt through its three chunked branches
+    (:562-632: chunk outputs are slices of the block's rows) -- and its decode row equals what the reference's decode branch holds at
+    [0, k, :] (exact position, pos_policy 0) and at [0, 0, :] (the literal index-0 fallback, pos_policy 1) (t3.py:440-486)."""
+    from chatterbox_vllm2_amd.prompt import assemble_prompt_ids
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb, synthetic_tensors
+    from chatterbox_vllm2_amd import constants as C
+    z = np.load(os.path.join(G, "prompt_embeds.npz")); tok = json.load(open(os.path.join(G, "tokenizer.json")))
+    assert list(z["constants"]) == [695, 696, 697, C.CONDITIONING_SIZE, C.SPEECH_TOKEN_OFFSET]        # t3.py:38-49, read from the imported module
+    assert np.array_equal(z["tri_5x7"], np.tril(np.ones((5, 7)), 0)[:, :7])                           # create_triangular_matrix: row j has j + 1 ones
+    cond = synthetic_cond_emb(1)
+    for key, vocab in (("en_english_ids", 704), ("en_mtl_ids", 2454), ("es_mtl_ids", 2454)):
+        m = oracle.OracleModel(1, vocab, max_pos=256).load(synthetic_tensors(1, vocab, 1234))
+        ec, eu = m.prompt_embeds(assemble_prompt_ids(tok[key]), cond)
+        assert np.array_equal(_crc_rows(torch.cat([ec, eu], dim=1)), z[f"full_{key}_crc"]), key
+        m.close()
+    m = oracle.OracleModel(1, 2454, max_pos=256).load(synthetic_tensors(1, 2454, 1234))
+    ids = assemble_prompt_ids(z["short_text_ids"].tolist())
+    assert ids == z["short_ids"].tolist()
+    ec, eu = m.prompt_embeds(ids, cond)
+    full = torch.cat([ec, eu], dim=1)
+    assert np.array_equal(full.view(torch.int16).numpy(), z["short_full"])
+    crc = _crc_rows(full); T = len(ids)
+    for k in (1, 10, 33, 34, 35, 40, T - 1):
+        assert np.array_equal(crc[:k], z[f"short_split{k}_a_crc"]) and np.array_equal(crc[k:], z[f"short_split{k}_b_crc"]), k
+    # split_prefill_decode (t3.py:340-421) as observed: a new block at every 695, decode ids (>= 2500) in runs of their own without multimodal rows
+    assert list(z["split_lengths"]) == [T, 39] and list(z["split_mm_rows"]) == [T, 39]
+    assert list(z["split3_lengths"]) == [T, 1, 39] and list(z["split3_is_decode"]) == [0, 1, 0]
+    # the decode branch as written (SURVEY.md 9 Q1): one token -> [1, 2048, 1024] (seq_len read from the channel dimension), two -> an error
+    assert list(z["decode_n1_shape"]) == [1, 2048, 1024] and bool(z["decode_n1_second_half_equal"]) and str(z["decode_n2_error"]) == "RuntimeError"
+    t = int(z["decode_token"])
+    assert np.array_equal(m.decode_embed(t, 0).view(torch.int16).numpy(), z["decode_n1_row0"])     # pos_policy 1
+    assert np.array_equal(m.decode_embed(t, 5).view(torch.int16).numpy(), z["decode_n1_row5"])     # pos_policy 0, fifth generated token
+    for pol in (0, 1):
+        gids, _ = m.generate(ids, cond, oracle.make_sampling(temperature=0.0, repetition_penalty=1.0, max_tokens=5, ignore_eos=True, pos_policy=pol), max_model_len=128)
+        assert gids == z[f"short_greedy_ids_policy{pol}"].tolist()
+        rows = torch.stack([torch.cat([m.decode_embed(gids[k - 1], k if pol == 0 else 0)] * 2) for k in range(1, 5)])
+        assert np.array_equal(_crc_rows(rows), z[f"short_decode_rows_policy{pol}_crc"])
+    m.close()
+
+
 def _hf_model(tensors, n_layers, dtype):
     from transformers import LlamaConfig, LlamaModel
     cfg = LlamaConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=n_layers, num_attention_heads=16,

@@ -1,6 +1,7 @@
 // Diagnostic: in-kernel phase timeline of the decode GEMMs in their real launch order (qkv -> o -> gate/up -> down over 30
 // layers of distinct weights, back to back on one stream).  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
-// -fhip-fp32-correctly-rounded-divide-sqrt -DT3_GEMM_CLK tools/gemm_clk.hip -o tools/gemm_clk
+// -fhip-fp32-correctly-rounded-divide-sqrt -std=c++17 -DT3_GEMM_CLK tools/gemm_clk.hip -o tools/gemm_clk
+// Reports the stamps of gemm2_kernel (the schedule the engine runs at <= 64-80 rows): entry, A staged, first weights, last MFMA, barrier, store.
 #include "../chatterbox-vllm2_amd/csrc/t3_kernels.hip"
 #include <algorithm>
 #include <cstdio>
@@ -61,35 +62,36 @@ int main(int argc, char** argv) {
     for (int w = 0; w < 3; ++w) if (!chain()) return 1;
     CK(hipStreamSynchronize(s));
     { static unsigned long long z[8][2048][5]; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_clk), z, sizeof(z))); }
+    { static unsigned long long z2[4][2048][6]; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm2_clk), z2, sizeof(z2))); }
     CK(hipEventRecord(e0, s));
     for (int w = 0; w < 5; ++w) if (!chain()) return 1;
     CK(hipEventRecord(e1, s));
     CK(hipStreamSynchronize(s));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("M=%d: %d launches, %.2f us per launch, %.1f us per layer (4 GEMMs, eager launches)\n", M, 5 * NL * 4, ms * 1e3 / (5 * NL * 4), ms * 1e3 / (5 * NL));
-    static unsigned long long clk[8][2048][5];
-    CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_gemm_clk), sizeof(clk)));
-    // the LAST launch of each class left its stamps: class = EPI*2 + (NW==16).  o and down share class 5 -> down (the later one) survives.
-    struct { int cls, wgs; const char* name; } K[] = {{EPI_BF16 * 2, (QKV / 16) * ((M + 15) / 16 / choose_mt(M, QKV / 16, 4, true)), "qkv (NORM, 4 waves)"},
-                                                        {EPI_SILU * 2, (F / 16) * ((M + 15) / 16 / choose_mt(M, F / 16, 4, true)), "gate/up (NORM, SiLU)"},
-                                                        {EPI_RESID * 2 + 1, (D / 16) * ((M + 15) / 16 / choose_mt(M, D / 16, 16, false)), "down (16 waves, +resid)"}};
-    for (auto& k : K) {
-        int n = 0; while (n < 2048 && clk[k.cls][n][0]) ++n;       // workgroups that left stamps (grid of the last launch of this class)
-        if (!n) continue;
-        unsigned long long t0min = ~0ull, t4max = 0;
-        for (int i = 0; i < n; ++i) { t0min = std::min(t0min, clk[k.cls][i][0]); t4max = std::max(t4max, clk[k.cls][i][4]); }
+    printf("M=%d: %d launches, %.2f us per launch, %.1f us per layer (4 GEMMs, eager launches, stamped build)\n", M, 5 * NL * 4, ms * 1e3 / (5 * NL * 4), ms * 1e3 / (5 * NL));
+    // gemm2_kernel (the current decode schedule): the LAST launch of each class left its stamps
+    static unsigned long long clk[4][2048][6];
+    CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_gemm2_clk), sizeof(clk)));
+    const char* names[4] = {"qkv (NORM, 4 waves)", "gate/up (NORM, SiLU, 4 waves)", "o (16 waves, +resid)", "down (16 waves, +resid)"};
+    for (int k = 0; k < 4; ++k) {
+        int n = 0; while (n < 2048 && clk[k][n][0]) ++n;       // workgroups that left stamps (grid of the last launch of this class)
+        if (!n) { printf("%s: no gemm2_kernel stamps (another schedule ran at this row count)\n", names[k]); continue; }
+        unsigned long long t0min = ~0ull, t5max = 0;
+        for (int i = 0; i < n; ++i) { t0min = std::min(t0min, clk[k][i][0]); t5max = std::max(t5max, clk[k][i][5]); }
         auto stat = [&](auto f, const char* what) {
-            std::vector<double> v; for (int i = 0; i < n; ++i) v.push_back(f(clk[k.cls][i]) / 100.0);
+            std::vector<double> v; for (int i = 0; i < n; ++i) v.push_back(f(clk[k][i]) / 100.0);
             std::sort(v.begin(), v.end());
-            printf("    %-34s min %6.2f  median %6.2f  p90 %6.2f  max %6.2f us\n", what, v[0], v[n / 2], v[n * 9 / 10], v[n - 1]);
+            printf("    %-44s min %6.2f  median %6.2f  p90 %6.2f  max %6.2f us\n", what, v[0], v[n / 2], v[n * 9 / 10], v[n - 1]);
         };
-        printf("%s: %d workgroups, first entry -> last exit %.2f us\n", k.name, n, (t4max - t0min) / 100.0);
+        printf("%s: %d workgroups, first entry -> last exit %.2f us\n", names[k], n, (t5max - t0min) / 100.0);
         stat([&](unsigned long long* c) { return (double)(c[0] - t0min); }, "entry after first workgroup");
-        stat([&](unsigned long long* c) { return (double)(c[1] - c[0]); }, "entry -> first tile consumed");
-        stat([&](unsigned long long* c) { return (double)(c[2] - c[1]); }, "rest of the K loop");
-        stat([&](unsigned long long* c) { return (double)(c[3] - c[2]); }, "LDS write + barrier");
-        stat([&](unsigned long long* c) { return (double)(c[4] - c[3]); }, "fold + epilogue + store");
-        stat([&](unsigned long long* c) { return (double)(c[4] - c[0]); }, "workgroup lifetime");
+        stat([&](unsigned long long* c) { return (double)(c[1] - c[0]); }, "entry -> A rows landed + staged in LDS");
+        stat([&](unsigned long long* c) { return (double)(c[2] - c[1]); }, "-> first weight k-block landed");
+        stat([&](unsigned long long* c) { return (double)(c[3] - c[2]); }, "-> last MFMA issued (rest of the K slice)");
+        stat([&](unsigned long long* c) { return (double)(c[4] - c[3]); }, "-> partials exchanged (LDS write + barrier)");
+        stat([&](unsigned long long* c) { return (double)(c[5] - c[4]); }, "-> fold + epilogue + store issued");
+        stat([&](unsigned long long* c) { return (double)(c[5] - c[0]); }, "workgroup lifetime");
+        stat([&](unsigned long long* c) { return (double)(c[5] - t0min); }, "exit time since the kernel's first entry");
     }
     return 0;
 }
