@@ -88,6 +88,8 @@ def hf_teacher_forced(tens, n_layers, ec, eu, ids, dtype, taps=()):
     the post-final-norm hidden rows [n, 2, 1024] and hidden states after `taps` layers [n, 2, 1024] (taps < n_layers)."""
     from transformers import DynamicCache
     w = dict(tens)
+    # one-token steps are GEMV-sized: more than a few OpenMP threads only add fork / join cost (and thrash badly on a shared box)
+    n_thr = torch.get_num_threads(); torch.set_num_threads(min(4, n_thr))
     hf = hf_model(tens, n_layers, dtype)
     head = w["speech_head.weight"].to(dtype)
     semb, spos = w["speech_emb.weight"].float(), w["speech_pos_emb.emb.weight"].float()
@@ -110,6 +112,7 @@ def hf_teacher_forced(tens, n_layers, ec, eu, ids, dtype, taps=()):
                 break
             x = (semb[ids[k]] + spos[k + 1]).to(torch.bfloat16)[None, None]        # decode embedding: a bf16 tensor in every run
             hs = step([x, x])
+    torch.set_num_threads(n_thr)
     return torch.stack(logits), torch.stack(hidden), {k: torch.stack(v) for k, v in tapped.items()}
 
 

@@ -118,18 +118,8 @@ def test_prompt_and_decode_embeddings_vs_reference_code(oracle):
 
 
 def _hf_model(tensors, n_layers, dtype):
-    from transformers import LlamaConfig, LlamaModel
-    cfg = LlamaConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=n_layers, num_attention_heads=16,
-                      num_key_value_heads=16, head_dim=64, rms_norm_eps=1e-5, rope_theta=500000.0, vocab_size=8,
-                      rope_scaling={"factor": 8.0, "high_freq_factor": 4.0, "low_freq_factor": 1.0,
-                                    "original_max_position_embeddings": 8192, "rope_type": "llama3"},
-                      max_position_embeddings=131072, attention_bias=False, mlp_bias=False, hidden_act="silu",
-                      attn_implementation="eager")
-    hf = LlamaModel(cfg).eval()
-    sd = {k[5:]: v.float() for k, v in tensors if k.startswith("tfmr.")}
-    sd["embed_tokens.weight"] = torch.zeros(8, 1024)
-    hf.load_state_dict(sd)
-    return hf.to(dtype)
+    import hf_gate
+    return hf_gate.hf_model(tensors, n_layers, dtype)
 
 
 @pytest.mark.parametrize("n_layers", [2, 6])
@@ -155,52 +145,86 @@ def test_oracle_vs_transformers_llama(oracle, n_layers):
     assert err_oracle < 1.5 * err_hf_bf16 + 1e-4, (err_oracle, err_hf_bf16)
 
 
-LOGIT_TOL = 0.10          # stated tolerance of the oracle's post-CFG logits against HF fp32 at 30 layers (observed max 0.075, logit std 0.70)
+LOGIT_TOL = 0.10          # stated tolerance of the oracle's post-CFG logits against HF fp32 at 30 layers (observed max 0.084 over 128 steps, logit std 0.72)
+GATE_STEPS = int(os.environ.get("T3_HF_GATE_STEPS", "32"))      # the committed evidence (hf_gate.npz) covers 128 steps of both prompts; 128 here takes ~10 minutes
 
 
-def test_logits_tolerance_vs_hf_fp32_30_layers(oracle):
-    """THE independent gate: the oracle's whole decode path -- both CFG streams, 30 layers, KV-cache decode with
-    the speech-position add (t3.py:440-480), final norm + speech head + `l_c + 0.5 (l_c - l_u)` (t3.py:650-662) -- against
-    transformers' LlamaModel in fp32 on the same synthetic weights, teacher-forced with the oracle's own greedy ids.
-      * max |oracle logit - HF fp32 logit| <= LOGIT_TOL at every step;
-      * the greedy id equals HF's argmax wherever HF's top-1 / top-2 margin exceeds 2 LOGIT_TOL (margin-aware: the reference
-        computes CFG in bf16, so near-ties can legitimately flip); the first divergence, if any, is reported with its margin.
-    Golden streams may only be regenerated while this test passes."""
-    from transformers import DynamicCache
-    from chatterbox_vllm2_amd.weights import synthetic_cond_emb, synthetic_tensors
-    NL, N = 30, 24
-    g = torch.Generator().manual_seed(77)          # the synthetic checkpoint has unit norm weights: give every RMSNorm a real one, so that
-    tens = [(k, (1.0 + 0.25 * torch.randn(v.shape, generator=g)).to(torch.bfloat16) if "norm" in k else v)      # the load-time fold W' = bf16(W * w_ln) is exercised
-            for k, v in synthetic_tensors(NL, 704, 1234)]
-    w = dict(tens)
-    m = oracle.OracleModel(NL, 704, max_pos=128).load(tens)
-    prompt = make_prompt(22, seed=5); cond = synthetic_cond_emb(1)
-    ids, lg = m.generate(prompt, cond, oracle.make_sampling(temperature=0.0, repetition_penalty=1.0, max_tokens=N, ignore_eos=True),
-                         want_logits=True, max_model_len=128)
+def _gate_case(name):
+    from chatterbox_vllm2_amd.prompt import assemble_prompt_ids
+    tok = json.load(open(os.path.join(G, "tokenizer.json")))
+    return {"p22": (704, make_prompt(22, seed=5)), "es": (2454, assemble_prompt_ids(tok["es_mtl_ids"]))}[name]
+
+
+@pytest.mark.parametrize("name", ["p22", "es"])
+def test_logits_gate_vs_hf_fp32_and_bf16_30_layers(oracle, name):
+    """THE independent gate, live: the oracle's whole decode path -- both CFG streams, 30 layers, KV-cache decode
+    with the speech-position add (t3.py:440-480), final norm + speech head + `l_c + 0.5 (l_c - l_u)` (t3.py:650-662) -- against
+    transformers' LlamaModel on the same weights (non-trivial RMSNorm weights), in fp32 AND in bf16 (the dtype the reference's vLLM
+    computes in), all teacher-forced with the oracle's greedy ids.  Per step:
+      * max |oracle logit - HF fp32 logit| <= LOGIT_TOL (absolute);
+      * mean |oracle - HF fp32| <= 1.5 x mean |HF bf16 - HF fp32| (the oracle is as close to the fp32 arithmetic as HF's own bf16 run);
+      * the greedy id equals HF fp32's argmax wherever HF's top-1 / top-2 margin exceeds 2 LOGIT_TOL (near-ties can legitimately flip:
+        the reference computes CFG in bf16);
+      * the top-p = 0.8 / T = 0.8 nucleus (the set that decides SAMPLED ids, tts.py:377) overlaps HF fp32's at least as well as
+        0.98 x HF bf16's does.
+    The first steps must also reproduce the committed run (ids, and HF's committed fp32 logits) -- hf_gate.npz, 128 steps of both prompts."""
+    import hf_gate as H
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb
+    vocab, prompt = _gate_case(name)
+    N = GATE_STEPS
+    cond = synthetic_cond_emb(1)
+    tens = H.gate_tensors(30, vocab)
+    ids, lg, _, _ = H.oracle_teacher_forced(oracle, tens, 30, vocab, prompt, cond, N)
+    m = oracle.OracleModel(30, vocab, max_pos=len(prompt) + 2).load(tens)
     ec, eu = m.prompt_embeds(prompt, cond)
     m.close()
-    hf = _hf_model(tens, NL, torch.float32)
-    head, semb, spos = w["speech_head.weight"].float(), w["speech_emb.weight"].float(), w["speech_pos_emb.emb.weight"].float()
-    caches = [DynamicCache(config=hf.config), DynamicCache(config=hf.config)]
-    ref = []
-    with torch.no_grad():
-        hs = [hf(inputs_embeds=e.float()[None], past_key_values=caches[s], use_cache=True).last_hidden_state[0, -1] for s, e in enumerate((ec, eu))]
-        for k in range(N):
-            lc, lu = hs[0] @ head.T, hs[1] @ head.T                      # fp32 final norm (inside LlamaModel) + speech head
-            ref.append(lc + 0.5 * (lc - lu))                             # t3.py:662 in fp32
-            if k == N - 1:
-                break
-            x = (semb[ids[k]] + spos[k + 1]).to(torch.bfloat16).float()  # decode embedding: speech_emb[tok] + speech_pos_emb[k+1], a bf16 tensor
-            hs = [hf(inputs_embeds=x[None, None], past_key_values=caches[s], use_cache=True).last_hidden_state[0, -1] for s in range(2)]
-    ref = torch.stack(ref)
-    err = (lg - ref).abs().max(dim=1).values
-    assert float(err.max()) <= LOGIT_TOL, f"max |oracle - HF fp32| per step: {[round(float(e), 4) for e in err]}"
-    top2 = ref.topk(2, dim=1)
-    margin = top2.values[:, 0] - top2.values[:, 1]
-    agree = top2.indices[:, 0] == torch.tensor(ids)
-    div = [(k, round(float(margin[k]), 4)) for k in range(N) if not agree[k]]
+    lg32, _, _ = H.hf_teacher_forced(tens, 30, ec, eu, ids, torch.float32)
+    lg16, _, _ = H.hf_teacher_forced(tens, 30, ec, eu, ids, torch.bfloat16)
+    c = H.compare(lg, lg32, lg16, ids)
+    assert float(c["err_max_oracle"].max()) <= LOGIT_TOL, [round(float(e), 4) for e in c["err_max_oracle"]]
+    ratio = c["err_mean_oracle"] / c["err_mean_hfbf16"]
+    assert float(ratio.max()) <= 1.5, f"mean logit error of the oracle / of HF bf16, per step: {[round(float(r), 3) for r in ratio]}"
+    div = [(k, round(float(c['hf32_margin'][k]), 4)) for k in range(N) if not c["agree_oracle"][k]]
     assert all(mg <= 2 * LOGIT_TOL for _, mg in div), f"greedy ids diverge from HF fp32 at (step, HF top-1/top-2 margin) {div}"
-    print(f"max logit error {float(err.max()):.4f} (std of logits {float(ref.std()):.3f}); greedy agreement {int(agree.sum())}/{N}; divergences {div}")
+    assert (c["nucleus_jaccard_oracle"] >= 0.98 * c["nucleus_jaccard_hfbf16"]).all(), (c["nucleus_jaccard_oracle"].min(), c["nucleus_jaccard_hfbf16"].min())
+    z = np.load(os.path.join(G, "hf_gate.npz"))
+    assert ids == z[f"{name}_ids"][:N].tolist()                                   # the committed 128-step run starts with this one
+    sel = [int(k) for k in z["sel_steps"] if k < N]
+    assert np.abs(lg32[sel].numpy() - z[f"{name}_hf32_logits"][:len(sel)]).max() < 1e-3      # HF fp32 here == HF fp32 when the fixture was made
+    print(f"{name}: {N} steps; max logit error {float(c['err_max_oracle'].max()):.4f} (HF bf16: {float(c['err_max_hfbf16'].max()):.4f}; logit std {float(c['hf32_logit_std']):.3f}); "
+          f"mean-error ratio max {float(ratio.max()):.3f}; greedy agreement {int(c['agree_oracle'].sum())}/{N}, divergences {div}; "
+          f"nucleus Jaccard min {float(c['nucleus_jaccard_oracle'].min()):.4f} (HF bf16 {float(c['nucleus_jaccard_hfbf16'].min()):.4f})")
+
+
+@pytest.mark.parametrize("name", ["p22", "es"])
+def test_oracle_vs_committed_hf_vectors(oracle, name):
+    """The pin that does not need `transformers` at test time: HF-fp32 hidden states after 1 / 2 / 30 layers and
+    post-CFG logits at steps 0, 1, 2 (the prefill's last row, two KV-cache decode steps), committed in hf_gate.npz by make_golden.py g4.
+    The oracle's residual stream must be as close to them as HF's own bf16 run was when the fixture was made (x1.5), its logits within
+    LOGIT_TOL; and the committed 128-step evidence must itself satisfy the gate's criteria."""
+    import hf_gate as H
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb
+    z = np.load(os.path.join(G, "hf_gate.npz"))
+    vocab, prompt = _gate_case(name)
+    assert prompt == z[f"{name}_prompt"].tolist()
+    sel = [int(k) for k in z["sel_steps"]]
+    tens = H.gate_tensors(30, vocab)
+    ids, lg, fin, taps = H.oracle_teacher_forced(oracle, tens, 30, vocab, prompt, synthetic_cond_emb(1), max(sel) + 1, taps=(1, 2))
+    assert ids == z[f"{name}_ids"][:len(ids)].tolist()
+    assert np.abs(lg[sel].numpy() - z[f"{name}_hf32_logits"]).max() <= LOGIT_TOL
+    nw = dict(tens)["tfmr.norm.weight"].float()
+    f32 = fin.float(); post = f32 * torch.rsqrt(f32.pow(2).mean(-1, keepdim=True) + 1e-5) * nw
+    errs = [np.abs(taps[1][sel].float().numpy() - z[f"{name}_hf32_hidden_l1"]).mean(), np.abs(taps[2][sel].float().numpy() - z[f"{name}_hf32_hidden_l2"]).mean(),
+            np.abs(post[sel].numpy() - z[f"{name}_hf32_hidden_l30_postnorm"]).mean()]
+    for depth, e, e16 in zip((1, 2, 30), errs, z[f"{name}_hidden_err_hfbf16"]):
+        assert e <= 1.5 * e16 + 1e-5, f"hidden state after {depth} layers: oracle {e:.5f} vs HF bf16 {e16:.5f} (mean abs error against HF fp32)"
+    # the committed evidence over all 128 steps
+    n = int(z["n_steps"])
+    assert len(z[f"{name}_ids"]) == n == 128
+    assert z[f"{name}_err_max_oracle"].max() <= LOGIT_TOL
+    assert (z[f"{name}_err_mean_oracle"] / z[f"{name}_err_mean_hfbf16"]).max() <= 1.5
+    assert all(z[f"{name}_hf32_margin"][k] <= 2 * LOGIT_TOL for k in range(n) if not z[f"{name}_agree_oracle"][k])
+    assert (z[f"{name}_nucleus_jaccard_oracle"] >= 0.98 * z[f"{name}_nucleus_jaccard_hfbf16"]).all()
 
 
 def test_norm_folded_gemm_matches_textbook(oracle):
