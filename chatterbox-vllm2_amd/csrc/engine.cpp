@@ -77,6 +77,8 @@ struct T3Engine {
     int n_groups = 1;
     int row_stride = 0;        // int32 words per row record
     bool fuse_rope = true;
+    bool fuse_qkv_small = false;      // T3_FUSE_QKV_SMALL=1: decode steps of 2 / 4 rows run the qkv projection + attention of a layer as one launch
+                                      // (bit-exact; measured SLOWER: 16 workgroups cannot pull the 6.3 MB of qkv weights fast enough)
 
     // weights (device)
     std::vector<LayerW> layers;
@@ -207,6 +209,7 @@ extern "C" int t3_create(const T3EngineConfig* cfg, T3Handle* out) {
         e->n_groups = std::max(1, std::min(g, std::min(8, cfg->max_seqs)));
         e->groups.resize(e->n_groups);
         if (const char* ev = getenv("T3_FUSE_ROPE")) e->fuse_rope = atoi(ev) != 0;
+        if (const char* ev = getenv("T3_FUSE_QKV_SMALL")) e->fuse_qkv_small = atoi(ev) != 0;
         if (const char* ev = getenv("T3_RUN_AHEAD")) e->run_ahead = atoi(ev) != 0;
         e->antiphase = e->n_groups == 2;
         if (const char* ev = getenv("T3_ANTIPHASE")) e->antiphase = atoi(ev) != 0 && e->n_groups == 2;
@@ -590,6 +593,18 @@ static int launch_attention_phase(T3Engine* e, T3Engine::Group& g, const T3Engin
     }
     return T3_OK;
 }
+// decode steps of one or two utterances: the qkv projection and the fused attention of a layer as ONE launch (a workgroup per head)
+static bool small_step_fuses(const T3Engine* e, const T3Engine::StepRec& sr) {
+    return e->fuse_qkv_small && e->fuse_rope && sr.n_prefill_rows == 0 && qkv_attention_small_fits(sr.M, (e->cfg.max_model_len + CHUNK - 1) / CHUNK);
+}
+static int launch_qkv_attention_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int L, hipStream_t s) {
+    const size_t layer_elems = (size_t)e->n_blocks * KV_BLOCK_ELEMS;
+    uint16_t* kvL = e->kv + (size_t)L * layer_elems;
+    Prof p(e, K_ATTN, s);
+    AttnArgs aa{nullptr, kvL, g.dm.rows, e->row_stride, g.att, sr.M, (e->cfg.max_model_len + CHUNK - 1) / CHUNK, g.qkv, kvL, e->cos_t, e->sin_t};
+    HIP_TRY(launch_qkv_attention_small(g.h, (const uint4*)e->layers[L].qkv, aa, s));
+    return T3_OK;
+}
 static int launch_mlp_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int L, hipStream_t s) {
     LayerW& y = e->layers[L];
     const int M = sr.M;
@@ -609,9 +624,14 @@ static int launch_sample_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::
 static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, hipStream_t s) {
     int rc;
     if ((rc = launch_embed_phase(e, g, sr, s))) return rc;
+    const bool fused_small = small_step_fuses(e, sr);
     for (int L = 0; L < e->cfg.n_layers; ++L) {
-        if ((rc = launch_qkv_phase(e, g, sr, L, s))) return rc;
-        if ((rc = launch_attention_phase(e, g, sr, L, s))) return rc;
+        if (fused_small) {
+            if ((rc = launch_qkv_attention_phase(e, g, sr, L, s))) return rc;
+        } else {
+            if ((rc = launch_qkv_phase(e, g, sr, L, s))) return rc;
+            if ((rc = launch_attention_phase(e, g, sr, L, s))) return rc;
+        }
         if ((rc = launch_mlp_phase(e, g, sr, L, s))) return rc;
     }
     return launch_sample_phase(e, g, sr, s);

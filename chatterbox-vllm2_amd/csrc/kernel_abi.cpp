@@ -150,10 +150,14 @@ extern "C" int t3k_rope_attention(const void* qkv, const int32_t* row_stream, co
  *     reads the K / V that launch s - 1 wrote through the fused path.
  * out [steps][rows][1024]; kv_new (nullable) [steps][rows][2][1024]: K (rotated) and V of the positions the launches wrote, read
  * back from the pool. */
-extern "C" int t3k_decode_attention(const void* ctx_qkv, int32_t n_content, int32_t content_rows, const void* new_qkv, const int32_t* ctx,
-                                    int32_t rows, int32_t steps, int32_t max_pos, int32_t waves, void* out, void* kv_new) {
+// new_rows: [steps][rows][3072] pre-RoPE qkv rows (wqkv_packed == nullptr: the fused attention kernel), or [steps][rows][1024] residual rows
+// with wqkv_packed = the packed, norm-folded qkv matrix on the host (the one-launch projection + attention kernel of small steps)
+static int decode_attention_impl(const void* ctx_qkv, int32_t n_content, int32_t content_rows, const void* new_rows, const uint16_t* wqkv_packed, const int32_t* ctx,
+                                 int32_t rows, int32_t steps, int32_t max_pos, int32_t waves, void* out, void* kv_new) {
+    const void* new_qkv = new_rows;
     if (!ctx_qkv || !new_qkv || !ctx || !out || rows <= 0 || steps <= 0 || n_content <= 0 || content_rows <= 0 || max_pos <= 0 ||
         (waves != 0 && waves != 4 && waves != 8)) return T3_E_INVALID;
+    if (wqkv_packed && !qkv_attention_small_fits(rows, (max_pos + CHUNK - 1) / CHUNK)) return T3_E_INVALID;
     for (int r = 0; r < rows; ++r)
         if (ctx[r] < 1 || ctx[r] - 1 > content_rows || ctx[r] - 1 + steps > max_pos) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
@@ -169,7 +173,9 @@ extern "C" int t3k_decode_attention(const void* ctx_qkv, int32_t n_content, int3
     rope_tables(max_pos, c.data(), s.data());
     const int stride = row_stride_words(max_blocks);
     DevBuf dctx, dnew, dc, ds, dq, dkv, dout, dkvn, drec_fill, drec;
-    K_TRY(dctx.from(ctx_qkv, (size_t)n_content * content_rows * QKV * 2)); K_TRY(dnew.from(new_qkv, (size_t)steps * rows * QKV * 2));
+    DevBuf dw;
+    if (wqkv_packed) K_TRY(dw.from(wqkv_packed, (size_t)QKV * D * 2));
+    K_TRY(dctx.from(ctx_qkv, (size_t)n_content * content_rows * QKV * 2)); K_TRY(dnew.from(new_qkv, (size_t)steps * rows * (wqkv_packed ? D : QKV) * 2));
     K_TRY(dc.from(c.data(), c.size() * 4)); K_TRY(ds.from(s.data(), s.size() * 4));
     K_TRY(dq.alloc((size_t)content_rows * D * 2));                     // rotated q of the fill rows: not used
     K_TRY(dkv.alloc((size_t)nb * KV_BLOCK_ELEMS * 2, true)); K_TRY(dout.alloc((size_t)steps * rows * D * 2, true));
@@ -205,13 +211,30 @@ extern "C" int t3k_decode_attention(const void* ctx_qkv, int32_t n_content, int3
         AttnArgs aa{nullptr, dkv.as<uint16_t>(), drec.as<int>(), stride, dout.as<uint16_t>() + (size_t)st * rows * D, rows, (max_pos + CHUNK - 1) / CHUNK,
                     dnew.as<uint16_t>() + (size_t)st * rows * QKV, dkv.as<uint16_t>(), dc.as<float>(), ds.as<float>()};
         aa.force_waves = waves;
-        K_TRY(launch_attention(aa, nullptr));
+        if (wqkv_packed) K_TRY(launch_qkv_attention_small(dnew.as<uint16_t>() + (size_t)st * rows * D, dw.as<uint4>(), aa, nullptr));
+        else K_TRY(launch_attention(aa, nullptr));
         K_TRY(launch_kv_gather(dkv.as<uint16_t>(), drec.as<int>(), stride, rows, dkvn.as<uint16_t>() + (size_t)st * rows * 2 * D, nullptr));
         K_TRY(hipDeviceSynchronize());
     }
     K_TRY(hipMemcpy(out, dout.p, (size_t)steps * rows * D * 2, hipMemcpyDeviceToHost));
     if (kv_new) K_TRY(hipMemcpy(kv_new, dkvn.p, (size_t)steps * rows * 2 * D * 2, hipMemcpyDeviceToHost));
     return T3_OK;
+}
+
+extern "C" int t3k_decode_attention(const void* ctx_qkv, int32_t n_content, int32_t content_rows, const void* new_qkv, const int32_t* ctx,
+                                    int32_t rows, int32_t steps, int32_t max_pos, int32_t waves, void* out, void* kv_new) {
+    return decode_attention_impl(ctx_qkv, n_content, content_rows, new_qkv, nullptr, ctx, rows, steps, max_pos, waves, out, kv_new);
+}
+
+/* The one-launch qkv projection + fused decode attention of small decode steps (2 or 4 rows): as t3k_decode_attention, but launch s takes the
+ * residual rows h[s][r] ([steps][rows][1024] bf16) and projects them itself: q | k | v = bf16(rstd * GEMM(h, bf16(Wqkv * ln_w))). */
+extern "C" int t3k_qkv_decode_attention(const void* ctx_qkv, int32_t n_content, int32_t content_rows, const void* h_rows, const void* ln_w, const void* wqkv,
+                                        const int32_t* ctx, int32_t rows, int32_t steps, int32_t max_pos, void* out, void* kv_new) {
+    if (!h_rows || !ln_w || !wqkv) return T3_E_INVALID;
+    std::vector<uint16_t> folded((size_t)QKV * D), packed((size_t)QKV * D);
+    fold_norm_weight((const uint16_t*)wqkv, QKV, D, (const uint16_t*)ln_w, folded.data());      // what the engine does once at load time
+    pack_weight(folded.data(), QKV, D, QKV, packed.data());
+    return decode_attention_impl(ctx_qkv, n_content, content_rows, h_rows, packed.data(), ctx, rows, steps, max_pos, 0, out, kv_new);
 }
 
 extern "C" int t3k_sample(const void* logits2, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg, uint32_t step,

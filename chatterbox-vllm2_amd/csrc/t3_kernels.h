@@ -95,6 +95,11 @@ struct AttnArgs {
     int force_waves = 0;       // 4 / 8: waves per (row, head) workgroup of the per-row kernel (0: by row count; parity tests check both)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+// Small decode steps (2 or 4 rows = 1 or 2 utterances): the qkv projection (RMSNorm folded) and the fused decode attention of a layer in ONE
+// launch, a workgroup of 16 waves per head.  x: the residual stream [rows][1024]; wqkv: the layer's packed, norm-folded qkv matrix; a: the
+// fused-form attention arguments (a.qkv is ignored: q / k / v never leave the workgroup).  Same numbers as gemm2_kernel + attention_kernel.
+bool qkv_attention_small_fits(int rows, int max_chunks);
+hipError_t launch_qkv_attention_small(const uint16_t* x, const uint4* wqkv, const AttnArgs& a, hipStream_t s);
 // parity hook: K (as stored, i.e. rotated) and V of every row's (stream, position) read back from the paged pool -> out [rows][2][1024]
 hipError_t launch_kv_gather(const uint16_t* kv_layer, const int* rowrec, int row_stride, int rows, uint16_t* out, hipStream_t s);
 

@@ -1504,6 +1504,262 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
     T3_ASTAMP(5);
 }
 // ------------------------------------------------------------------------------------------------
+// Small decode steps (R = 2 or 4 rows: one or two utterances, the reference server's own regime): qkv projection + fused decode
+// attention of a layer in ONE launch.  At these sizes a step is a chain of ~155 launches of 3-8 us each, and the qkv GEMM and the
+// attention are the one pair of neighbours whose seam is not all-to-all: head h's attention needs only head h's 192 columns of qkv.
+// One workgroup of 16 waves per head:
+//   phase 1 (GEMM, the numbers of gemm2_kernel's NORM form): wave = (K segment s = wave & 3, tile group g = wave >> 2); a wave folds its
+//     256-wide segment of 3 of the head's 12 n-tiles (q 0-3, k 4-7, v 8-11) with one MFMA chain per tile from +0 in ascending k; the
+//     segments of a tile fold ((s0 + s1) + s2) + s3 through LDS; row statistic from the MFMA diagonal (waves g = 0), rstd in the epilogue;
+//     q / k / v of the R rows stay in LDS as bf16.
+//   phase 2 (attention, the numbers of attention_kernel<16 / R, nt, FUSE>): 16 / R waves per row take the row's chunks round-robin; RoPE
+//     of q / k, paged write of the newest K / V, scores and P.V on the matrix cores, per-chunk partials in LDS, ascending-chunk fold.
+// The waves request their first K/V tile as soon as their weight registers are free, before the cross-segment fold: the tile's HBM round
+// trip runs under the fold and the barriers, and no kernel boundary sits between the projection and the attention.
+// MEASURED (round 3, B = 1, max_model_len 400): bit-exact with the two launches and SLOWER -- 19.8 us per evented launch against 7.4 + 10.1,
+// 1.010 against 0.839 ms per step (990 against 1 193 tok/s; B = 2: 1 760 against 2 354).  A workgroup per head is 16 CUs for 6.3 MB of
+// weights, 384 KB each, and one CU takes in ~50 GB/s: the projection alone lasts ~8 us there, against ~3.3 us spread over 192 CUs.  The
+// engine therefore keeps the two launches (T3_FUSE_QKV_SMALL=1 selects this kernel); its parity cases stay (t3k_qkv_decode_attention).
+// ------------------------------------------------------------------------------------------------
+struct QkvAttnArgs { const uint16_t* x; const uint4* wqkv; AttnArgs a; };
+constexpr int QA_PART_FLOATS = 12 * 4 * 4 * 64;           // [tile 12][segment 4][reg 4][lane 64] fp32 partials of the GEMM phase
+constexpr size_t qkv_attn_lds_floats(int R, int max_chunks) {
+    const size_t attn = (size_t)R * 66 * max_chunks + 16 * (96 + 12 * 64);      // per row m | l | o partials; per wave scores / probabilities / newest k, v
+    const size_t gemm = QA_PART_FLOATS + 4 * 16;                                 // partials + row statistic; aliased by the attention regions
+    return (attn > gemm ? attn : gemm) + (size_t)R * 96 + 4;                     // + q / k / v rows (bf16 [R][192]) + rstd pad
+}
+template <int R>
+__global__ __launch_bounds__(1024) void qkv_attention_kernel(QkvAttnArgs p) {
+    static_assert(R == 2 || R == 4, "one or two utterances");
+    constexpr int WPR = 16 / R;                              // waves per row in the attention phase
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const AttnArgs& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform values stay in scalar registers
+    const int col = lane & 15, kg = lane >> 4;
+    const int h = blockIdx.x;
+    const size_t big = qkv_attn_lds_floats(R, a.max_chunks) - (size_t)R * 96 - 4;
+    uint16_t* qkv_s = reinterpret_cast<uint16_t*>(lds + big);          // [R][192] bf16: q | k | v of this head, pre-RoPE
+    float* part = lds;                                                 // GEMM phase
+    float* rowsum = lds + QA_PART_FLOATS;                              // [4 segments][16 rows]
+
+    // ---------------- phase 1: this head's 192 columns of the qkv projection
+    {
+        const int sseg = wave & 3, g = wave >> 2;
+        const int m = col < R ? col : R - 1;                           // padded rows re-read the last row; their outputs are dropped
+        const uint4* xp = reinterpret_cast<const uint4*>(p.x + (size_t)m * D + sseg * 256 + kg * 8);
+        uint4 af[8];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) af[kb] = xp[kb * 4];
+        f32x4 acc[3], ss = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int j = 3 * g + t, nt = (j >> 2) * 64 + h * 4 + (j & 3);             // packed n-tile of the [3072][1024] matrix: q rows 0.., k rows 1024.., v rows 2048..
+            const uint4* wp = p.wqkv + ((size_t)nt * 32 + sseg * 8) * 64 + lane;
+            uint4 w[8];
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) w[kb] = ld_nt(wp + kb * 64);
+            acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[kb]), as_frag(w[kb]), acc[t], 0, 0, 0);
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) ss = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[kb]), as_frag(af[kb]), ss, 0, 0, 0);   // diagonal = sum of squares of the segment
+            const int r = col & 3;
+            const float d = r == 0 ? ss[0] : r == 1 ? ss[1] : r == 2 ? ss[2] : ss[3];
+            if ((col >> 2) == kg) rowsum[sseg * 16 + col] = d;
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(((3 * g + t) * 4 + sseg) * 4 + r) * 64 + lane] = acc[t][r];
+    }
+    // ---------------- attention set-up that does not need q / k / v: the wave's row, its chunks, its first tile (in flight across the fold)
+    const int row = wave / WPR, w = wave % WPR;
+    const int* rec = a.rowrec + (size_t)row * a.row_stride;
+    const int L = rec[1] + 1;
+    const int nc = (L + CHUNK - 1) / CHUNK;
+    const int* bt = rec + ROW_HDR;
+    constexpr int CPB = KV_BLOCK / CHUNK;
+    uint4 kf[8], vf[8];
+    auto load_tiles = [&](int c) {
+        const int blk = bt[c / CPB], ci = c % CPB;
+        const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 0, h) + (size_t)ci * (CHUNK * HD)) + lane;
+        const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 1, h) + (size_t)ci * (CHUNK * HD)) + lane;
+        const int npool = L - 1 - c * CHUNK;                           // tokens of this chunk that live in the pool (the newest one comes from LDS)
+        if (npool >= CHUNK) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) kf[f] = ld_nt(Kp + f * 64);
+#pragma unroll
+            for (int f = 0; f < 8; ++f) vf[f] = ld_nt(Vp + f * 64);
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                if (16 * tt < npool) { kf[2 * tt] = ld_nt(Kp + (2 * tt) * 64); kf[2 * tt + 1] = ld_nt(Kp + (2 * tt + 1) * 64); }
+                else { kf[2 * tt] = make_uint4(0, 0, 0, 0); kf[2 * tt + 1] = make_uint4(0, 0, 0, 0); }
+            }
+#pragma unroll
+            for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    if (32 * ts < npool) vf[2 * dt + ts] = ld_nt(Vp + (2 * dt + ts) * 64);
+                    else vf[2 * dt + ts] = make_uint4(0, 0, 0, 0);
+                }
+        }
+    };
+    if (w < nc) load_tiles(w);
+    __syncthreads();
+    // ---------------- cross-segment fold + rstd: q / k / v rows of this head as bf16, in LDS
+    if (tid < R * 192) {
+        const int r_ = tid / 192, c_ = tid % 192, j = c_ >> 4, cc = c_ & 15;
+        const int o = (r_ & 3) * 64 + 16 * (r_ >> 2) + cc;             // D[row = 4 (lane >> 4) + reg][col = lane & 15]
+        const float* pj = part + (size_t)j * 4 * 4 * 64;
+        const float v = ((pj[o] + pj[256 + o]) + pj[512 + o]) + pj[768 + o];
+        const float ssum = ((rowsum[r_] + rowsum[16 + r_]) + rowsum[32 + r_]) + rowsum[48 + r_];
+        const float rstd = 1.0f / sqrtf(ssum * (1.0f / 1024.0f) + 1e-5f);
+        qkv_s[r_ * 192 + c_] = (uint16_t)f2bf(v * rstd);
+    }
+    __syncthreads();                                                   // q / k / v are in place; the partials are dead: their LDS becomes the attention regions
+    // ---------------- phase 2: fused decode attention of row `row`, head h, by the row's WPR waves
+    float* pm = lds + (size_t)row * 66 * a.max_chunks; float* pl = pm + a.max_chunks; float* po = pm + 2 * a.max_chunks;
+    float* sbuf = lds + (size_t)R * 66 * a.max_chunks + wave * 96;
+    uint32_t* stash = reinterpret_cast<uint32_t*>(lds + (size_t)R * 66 * a.max_chunks + 16 * 96) + wave * (12 * 64) + lane;
+    uint16_t* pbuf = reinterpret_cast<uint16_t*>(sbuf + 64);
+    uint4 qfrag[2], knf[2];
+    uint32_t vnew[4];
+    {
+        const int pos = L - 1;
+        const uint16_t* src = qkv_s + row * 192;
+        float c[8], s[8];
+        {
+            const float4* cp = reinterpret_cast<const float4*>(a.cos_t + (size_t)pos * 32 + kg * 8);
+            const float4* sp = reinterpret_cast<const float4*>(a.sin_t + (size_t)pos * 32 + kg * 8);
+            const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+            c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+            s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
+        }
+        rope8(*reinterpret_cast<const uint4*>(src + kg * 8), *reinterpret_cast<const uint4*>(src + 32 + kg * 8), c, s, qfrag[0], qfrag[1]);
+        rope8(*reinterpret_cast<const uint4*>(src + 64 + kg * 8), *reinterpret_cast<const uint4*>(src + 96 + kg * 8), c, s, knf[0], knf[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vnew[dt] = src[128 + 16 * dt + col];
+        if (w == 0) {                               // paged write of the newest K / V (for the following steps)
+            const int blk = bt[pos / KV_BLOCK], tok = pos % KV_BLOCK;
+            uint16_t* kb = a.kv_layer_w + kv_head_base(blk, 0, h);
+            uint16_t* vb = a.kv_layer_w + kv_head_base(blk, 1, h);
+            if (col == 0) {
+                *reinterpret_cast<uint4*>(kb + k_slot(tok, 0, kg)) = knf[0];
+                *reinterpret_cast<uint4*>(kb + k_slot(tok, 1, kg)) = knf[1];
+            }
+            if (kg == 0) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) vb[v_elem(tok, 16 * dt + col)] = (uint16_t)vnew[dt];
+            }
+        }
+        stash[0 * 64] = knf[0].x; stash[1 * 64] = knf[0].y; stash[2 * 64] = knf[0].z; stash[3 * 64] = knf[0].w;
+        stash[4 * 64] = knf[1].x; stash[5 * 64] = knf[1].y; stash[6 * 64] = knf[1].z; stash[7 * 64] = knf[1].w;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) stash[(8 + dt) * 64] = vnew[dt];
+        asm volatile("" ::: "memory");
+    }
+    for (int c = w; c < nc; c += WPR) {
+        if (c != w) load_tiles(c);
+        if (c == nc - 1) {                          // the newest token is patched into the last tile
+            knf[0] = make_uint4(stash[0 * 64], stash[1 * 64], stash[2 * 64], stash[3 * 64]);
+            knf[1] = make_uint4(stash[4 * 64], stash[5 * 64], stash[6 * 64], stash[7 * 64]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) vnew[dt] = stash[(8 + dt) * 64];
+            const int tc = L - 1 - c * CHUNK;
+            const int tts = tc >> 4, ts = tc & 15, tss = tc >> 5, kgs = (tc & 31) >> 3, js = tc & 7;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const bool hit = (tt == tts) && (col == ts);
+                kf[2 * tt].x = hit ? knf[0].x : kf[2 * tt].x; kf[2 * tt].y = hit ? knf[0].y : kf[2 * tt].y;
+                kf[2 * tt].z = hit ? knf[0].z : kf[2 * tt].z; kf[2 * tt].w = hit ? knf[0].w : kf[2 * tt].w;
+                kf[2 * tt + 1].x = hit ? knf[1].x : kf[2 * tt + 1].x; kf[2 * tt + 1].y = hit ? knf[1].y : kf[2 * tt + 1].y;
+                kf[2 * tt + 1].z = hit ? knf[1].z : kf[2 * tt + 1].z; kf[2 * tt + 1].w = hit ? knf[1].w : kf[2 * tt + 1].w;
+            }
+            if (kg == kgs) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    if (tss == 0) patch16(vf[2 * dt], js, vnew[dt]); else patch16(vf[2 * dt + 1], js, vnew[dt]);
+                }
+            }
+        }
+        f32x4 sacc[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            sacc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            sacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf[2 * tt]), as_frag(qfrag[0]), sacc[tt], 0, 0, 0);
+            sacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf[2 * tt + 1]), as_frag(qfrag[1]), sacc[tt], 0, 0, 0);
+        }
+        if (col == 0) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                *reinterpret_cast<float4*>(sbuf + 16 * tt + 4 * kg) = make_float4(sacc[tt][0], sacc[tt][1], sacc[tt][2], sacc[tt][3]);
+        }
+        asm volatile("" ::: "memory");
+        const bool live = (c * CHUNK + lane) < L;
+        const float sc = live ? sbuf[lane] * 0.125f : -INFINITY;
+        const float m = wave_max_f32(sc, lane);
+        const float pr = live ? t3_expf(sc - m) : 0.0f;
+        const float lsum = wave_bfly_add_f32(pr, lane);
+        pbuf[lane] = (pr < 0x1p-100f) ? (uint16_t)0 : (uint16_t)f2bf(pr);
+        asm volatile("" ::: "memory");
+        uint4 pfrag[2];
+        pfrag[0] = *reinterpret_cast<const uint4*>(pbuf + 8 * kg);
+        pfrag[1] = *reinterpret_cast<const uint4*>(pbuf + 32 + 8 * kg);
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf[2 * dt]), as_frag(pfrag[0]), oacc[dt], 0, 0, 0);
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf[2 * dt + 1]), as_frag(pfrag[1]), oacc[dt], 0, 0, 0);
+        }
+        if (col == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<float4*>(po + c * 64 + 16 * dt + 4 * kg) = make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
+        }
+        if (lane == 0) { pm[c] = m; pl[c] = lsum; }
+        asm volatile("" ::: "memory");
+    }
+    __syncthreads();
+    if (w == 0) {                                   // fold in ascending chunk order (contract), as attention_kernel does
+        float M = -INFINITY;
+        for (int c0 = 0; c0 < nc; c0 += 64) M = fmaxf(M, (c0 + lane < nc) ? pm[c0 + lane] : -INFINITY);
+        M = wave_max_f32(M, lane);
+        for (int c0 = 0; c0 < nc; c0 += 64) if (c0 + lane < nc) pm[c0 + lane] = t3_expf(pm[c0 + lane] - M);
+        asm volatile("" ::: "memory");
+        float l = 0.0f, o = 0.0f;
+        for (int c = 0; c < nc; ++c) {
+            const float wgt = pm[c];
+            l = __builtin_fmaf(wgt, pl[c], l);
+            o = __builtin_fmaf(wgt, po[c * 64 + lane], o);
+        }
+        a.out[(size_t)row * D + h * HD + lane] = (uint16_t)f2bf(o / l);
+    }
+}
+bool qkv_attention_small_fits(int rows, int max_chunks) {
+    return (rows == 2 || rows == 4) && qkv_attn_lds_floats(rows, max_chunks) * sizeof(float) <= 160 * 1024;
+}
+hipError_t launch_qkv_attention_small(const uint16_t* x, const uint4* wqkv, const AttnArgs& a, hipStream_t s) {
+    if (!qkv_attention_small_fits(a.rows, a.max_chunks)) return hipErrorInvalidValue;
+    const size_t lds = qkv_attn_lds_floats(a.rows, a.max_chunks) * sizeof(float);
+    QkvAttnArgs p{x, wqkv, a};
+    static size_t raised[MAX_DEVICES][2] = {};
+    size_t& have = raised[cur_device()][a.rows == 4];
+    if (lds > 64 * 1024 && lds > have) {
+        hipError_t e = a.rows == 2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_attention_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                   : hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_attention_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        have = lds;
+    }
+    if (a.rows == 2) hipLaunchKernelGGL(qkv_attention_kernel<2>, dim3(H), dim3(1024), lds, s, p);
+    else hipLaunchKernelGGL(qkv_attention_kernel<4>, dim3(H), dim3(1024), lds, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Prefill form of the same attention: one workgroup per (head, 16 consecutive rows of the launch).  The decode kernel replicates
 // one q over the 16 B-operand columns of the MFMA; here the 16 columns are 16 different rows (positions) of one stream, so a K/V
 // tile is read once per 16 rows instead of once per row.  An MFMA output column depends on its own B column only, so every
