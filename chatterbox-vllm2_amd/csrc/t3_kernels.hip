@@ -1350,7 +1350,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
         rope8(*reinterpret_cast<const uint4*>(src + D + kg * 8), *reinterpret_cast<const uint4*>(src + D + 32 + kg * 8), c, s, knf[0], knf[1]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) vnew[dt] = src[2 * D + 16 * dt + col];
-        if (wave == 0) {                            // paged write of the newest K / V (for the following steps)
+#if defined(T3_ATTN_NOKVWRITE) || defined(T3_ATTN_K_TILE_WRITE)
+        if (false) {                                // NOKVWRITE: timing diagnostic only (the following steps read stale K / V); K_TILE_WRITE: K goes back from the chunk loop
+#else
+        if (wave == 0) {                            // paged write of the newest K (8 pieces of 16 bytes, early: their latency hides under the tile stream)
+#endif
             const int blk = bt[pos / KV_BLOCK], tok = pos % KV_BLOCK;
             uint16_t* kb = a.kv_layer_w + kv_head_base(blk, 0, h);
             uint16_t* vb = a.kv_layer_w + kv_head_base(blk, 1, h);
@@ -1358,10 +1362,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
                 *reinterpret_cast<uint4*>(kb + k_slot(tok, 0, kg)) = knf[0];
                 *reinterpret_cast<uint4*>(kb + k_slot(tok, 1, kg)) = knf[1];
             }
+#ifdef T3_ATTN_V_ELEMENT_WRITES      // the round-2 form: 64 two-byte stores per (row, head)
             if (kg == 0) {
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) vb[v_elem(tok, 16 * dt + col)] = (uint16_t)vnew[dt];
             }
+#else
+            (void)vb;                              // V goes back as whole 16-byte pieces from the wave that holds the last tile (chunk loop)
+#endif
         }
     } else {
         const uint16_t* qsrc = a.q + (size_t)row * D + h * HD + kg * 8;
@@ -1402,11 +1410,40 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
                 kf[2 * tt + 1].x = hit ? knf[1].x : kf[2 * tt + 1].x; kf[2 * tt + 1].y = hit ? knf[1].y : kf[2 * tt + 1].y;
                 kf[2 * tt + 1].z = hit ? knf[1].z : kf[2 * tt + 1].z; kf[2 * tt + 1].w = hit ? knf[1].w : kf[2 * tt + 1].w;
             }
+#if defined(T3_ATTN_K_TILE_WRITE) && !defined(T3_ATTN_NOKVWRITE)
+            // Diagnostic variant: the newest K written back from the patched tile as full lines (the lanes of the token's aligned 8-token group,
+            // per (dim half, dim octet) 128 contiguous bytes) instead of 8 pieces of 16 bytes from the prologue.  Bit-exact and 0.3 % SLOWER at C3
+            // (20.48 against 20.54 k tok/s): these stores come late in the workgroup's life and their latency is no longer hidden.
+            if ((col >> 3) == (ts >> 3)) {
+                const int blkk = bt[c / CPB], cik = c % CPB;
+                uint4* Kw = reinterpret_cast<uint4*>(a.kv_layer_w + kv_head_base(blkk, 0, h) + (size_t)cik * (CHUNK * HD)) + lane;
+                if (tts == 0) { Kw[0 * 64] = kf[0]; Kw[1 * 64] = kf[1]; }
+                else if (tts == 1) { Kw[2 * 64] = kf[2]; Kw[3 * 64] = kf[3]; }
+                else if (tts == 2) { Kw[4 * 64] = kf[4]; Kw[5 * 64] = kf[5]; }
+                else { Kw[6 * 64] = kf[6]; Kw[7 * 64] = kf[7]; }
+            }
+#endif
             if (kg == kgs) {
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     if (tss == 0) patch16(vf[2 * dt], js, vnew[dt]); else patch16(vf[2 * dt + 1], js, vnew[dt]);
                 }
+#if !defined(T3_ATTN_V_ELEMENT_WRITES) && !defined(T3_ATTN_NOKVWRITE)
+                // Paged write of the newest V: V is stored token-minor (a lane's 16 bytes = 8 consecutive tokens of one dim), so one token is 64
+                // two-byte elements 16 bytes apart.  The patched pieces of this tile ARE the pool's content with the new token merged in: the 16
+                // lanes of the token's group write theirs back whole -- per dim tile 256 contiguous bytes (two full lines) instead of 16 partial
+                // writes.  Measured at C3 on one box: no K / V write at all 20.88 k tok/s (a bound, not a kernel), element writes (round 2) 20.34 k,
+                // this form 20.54 k.
+                const int blk = bt[c / CPB], ci = c % CPB;
+                uint4* Vw = reinterpret_cast<uint4*>(a.kv_layer_w + kv_head_base(blk, 1, h) + (size_t)ci * (CHUNK * HD)) + lane;
+                if (tss == 0) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) Vw[(2 * dt) * 64] = vf[2 * dt];
+                } else {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) Vw[(2 * dt + 1) * 64] = vf[2 * dt + 1];
+                }
+#endif
             }
         }
 #ifdef T3_ATTN_DRY

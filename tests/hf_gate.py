@@ -46,10 +46,11 @@ def nucleus(logits: torch.Tensor, temperature=0.8, top_p=0.8) -> torch.Tensor:
     return keep
 
 
-def oracle_teacher_forced(oracle, tens, n_layers, vocab, prompt, cond, n_steps, taps=()):
+def oracle_teacher_forced(oracle, tens, n_layers, vocab, prompt, cond, n_steps, taps=(), tap_steps=None, want_embeds=False):
     """The oracle's greedy decode driven row by row (prefill rows of both CFG streams, then one row pair per step), so that the
     residual stream can be tapped after any number of layers.  Returns ids, post-CFG logits [n, 8194], the conditional / unconditional
-    final residual rows [n, 2, 1024] and the tapped rows {layers: [n, 2, 1024]} of the row that produces each step's logits."""
+    final residual rows [n, 2, 1024] and the tapped rows {layers: [tap_steps, 2, 1024]} of the row that produces each step's logits
+    (tap_steps: only the first so many steps are tapped; a tap costs one more pass over the rows); want_embeds: also (ec, eu)."""
     w = dict(tens)
     T = len(prompt)
     m = oracle.OracleModel(n_layers, vocab, max_pos=T + n_steps + 2).load(tens)
@@ -58,15 +59,15 @@ def oracle_teacher_forced(oracle, tens, n_layers, vocab, prompt, cond, n_steps, 
     tapped = {k: [] for k in taps}
     finals, ids, logits = [], [], []
 
-    def run(h, rs_, rp_, pick):
+    def run(h, rs_, rp_, pick, step):
         out = None
-        for k in taps:                                # one pass per tap (the oracle taps one layer per call); KV writes are idempotent
+        for k in (taps if tap_steps is None or step < tap_steps else ()):      # one pass per tap (the oracle taps one layer per call); KV writes are idempotent
             _, t = m.forward_rows(h, rs_, rp_, tap_layer=k)
             tapped[k].append(t[pick].clone())
         out, _ = m.forward_rows(h, rs_, rp_)
         return out[pick]
 
-    hcu = run(rows, rs, rp, [T - 1, 2 * T - 1])
+    hcu = run(rows, rs, rp, [T - 1, 2 * T - 1], 0)
     semb, spos = w["speech_emb.weight"].float(), w["speech_pos_emb.emb.weight"].float()
     for k in range(n_steps):
         finals.append(hcu.clone())
@@ -77,9 +78,10 @@ def oracle_teacher_forced(oracle, tens, n_layers, vocab, prompt, cond, n_steps, 
         if k == n_steps - 1:
             break
         x = (semb[tok] + spos[k + 1]).to(torch.bfloat16)
-        hcu = run(torch.stack([x, x]), [0, 1], [T + k, T + k], [0, 1])
+        hcu = run(torch.stack([x, x]), [0, 1], [T + k, T + k], [0, 1], k + 1)
     m.close()
-    return ids, torch.stack(logits), torch.stack(finals), {k: torch.stack(v) for k, v in tapped.items()}
+    res = (ids, torch.stack(logits), torch.stack(finals), {k: torch.stack(v) for k, v in tapped.items()})
+    return res + ((ec, eu),) if want_embeds else res
 
 
 def hf_teacher_forced(tens, n_layers, ec, eu, ids, dtype, taps=()):

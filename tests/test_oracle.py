@@ -145,8 +145,9 @@ def test_oracle_vs_transformers_llama(oracle, n_layers):
     assert err_oracle < 1.5 * err_hf_bf16 + 1e-4, (err_oracle, err_hf_bf16)
 
 
-LOGIT_TOL = 0.10          # stated tolerance of the oracle's post-CFG logits against HF fp32 at 30 layers (observed max 0.084 over 128 steps, logit std 0.72)
-GATE_STEPS = int(os.environ.get("T3_HF_GATE_STEPS", "32"))      # the committed evidence (hf_gate.npz) covers 128 steps of both prompts; 128 here takes ~10 minutes
+LOGIT_TOL = 0.10          # stated tolerance of the oracle's post-CFG logits against HF fp32 at 30 layers (observed max 0.089 over 128 steps x 2 prompts, logit std 0.72-0.84)
+GATE_STEPS = int(os.environ.get("T3_HF_GATE_STEPS", "32"))      # the committed evidence (hf_gate.npz) covers 128 steps of both prompts; 128 here takes ~10 minutes per prompt
+GATE_LIVE = ("p22", "es") if os.environ.get("T3_HF_GATE_STEPS") else ("p22",)     # by default the es prompt is checked against the committed HF vectors only (CPU-suite time)
 
 
 def _gate_case(name):
@@ -155,7 +156,24 @@ def _gate_case(name):
     return {"p22": (704, make_prompt(22, seed=5)), "es": (2454, assemble_prompt_ids(tok["es_mtl_ids"]))}[name]
 
 
-@pytest.mark.parametrize("name", ["p22", "es"])
+_GATE_RUNS = {}
+
+
+def _gate_run(oracle, name):
+    """One teacher-forced oracle run per prompt, shared by the live gate and the committed-vector pin (a 30-layer load + prefill is ~1 min)."""
+    import hf_gate as H
+    from chatterbox_vllm2_amd.weights import synthetic_cond_emb
+    if name not in _GATE_RUNS:
+        vocab, prompt = _gate_case(name)
+        n = GATE_STEPS if name in GATE_LIVE else 3
+        tens = H.gate_tensors(30, vocab)
+        ids, lg, fin, taps, (ec, eu) = H.oracle_teacher_forced(oracle, tens, 30, vocab, prompt, synthetic_cond_emb(1), n, taps=(1, 2) if name == "p22" else (),
+                                                               tap_steps=3, want_embeds=True)
+        _GATE_RUNS[name] = dict(tens=tens, ids=ids, lg=lg, fin=fin, taps=taps, ec=ec, eu=eu, prompt=prompt)
+    return _GATE_RUNS[name]
+
+
+@pytest.mark.parametrize("name", GATE_LIVE)
 def test_logits_gate_vs_hf_fp32_and_bf16_30_layers(oracle, name):
     """THE independent gate, live: the oracle's whole decode path -- both CFG streams, 30 layers, KV-cache decode
     with the speech-position add (t3.py:440-480), final norm + speech head + `l_c + 0.5 (l_c - l_u)` (t3.py:650-662) -- against
@@ -167,23 +185,17 @@ def test_logits_gate_vs_hf_fp32_and_bf16_30_layers(oracle, name):
         the reference computes CFG in bf16);
       * the top-p = 0.8 / T = 0.8 nucleus (the set that decides SAMPLED ids, tts.py:377) overlaps HF fp32's at least as well as
         0.98 x HF bf16's does.
-    The first steps must also reproduce the committed run (ids, and HF's committed fp32 logits) -- hf_gate.npz, 128 steps of both prompts."""
+    The steps must also reproduce the committed run (ids, and HF's committed fp32 logits): hf_gate.npz holds 128 steps of this prompt and of
+    the 141-row es prompt (T3_HF_GATE_STEPS=128 runs both live at that length)."""
     import hf_gate as H
-    from chatterbox_vllm2_amd.weights import synthetic_cond_emb
-    vocab, prompt = _gate_case(name)
-    N = GATE_STEPS
-    cond = synthetic_cond_emb(1)
-    tens = H.gate_tensors(30, vocab)
-    ids, lg, _, _ = H.oracle_teacher_forced(oracle, tens, 30, vocab, prompt, cond, N)
-    m = oracle.OracleModel(30, vocab, max_pos=len(prompt) + 2).load(tens)
-    ec, eu = m.prompt_embeds(prompt, cond)
-    m.close()
-    lg32, _, _ = H.hf_teacher_forced(tens, 30, ec, eu, ids, torch.float32)
-    lg16, _, _ = H.hf_teacher_forced(tens, 30, ec, eu, ids, torch.bfloat16)
+    r = _gate_run(oracle, name)
+    ids, lg, N = r["ids"], r["lg"], len(r["ids"])
+    lg32, _, _ = H.hf_teacher_forced(r["tens"], 30, r["ec"], r["eu"], ids, torch.float32)
+    lg16, _, _ = H.hf_teacher_forced(r["tens"], 30, r["ec"], r["eu"], ids, torch.bfloat16)
     c = H.compare(lg, lg32, lg16, ids)
     assert float(c["err_max_oracle"].max()) <= LOGIT_TOL, [round(float(e), 4) for e in c["err_max_oracle"]]
     ratio = c["err_mean_oracle"] / c["err_mean_hfbf16"]
-    assert float(ratio.max()) <= 1.5, f"mean logit error of the oracle / of HF bf16, per step: {[round(float(r), 3) for r in ratio]}"
+    assert float(ratio.max()) <= 1.5, f"mean logit error of the oracle / of HF bf16, per step: {[round(float(x), 3) for x in ratio]}"
     div = [(k, round(float(c['hf32_margin'][k]), 4)) for k in range(N) if not c["agree_oracle"][k]]
     assert all(mg <= 2 * LOGIT_TOL for _, mg in div), f"greedy ids diverge from HF fp32 at (step, HF top-1/top-2 margin) {div}"
     assert (c["nucleus_jaccard_oracle"] >= 0.98 * c["nucleus_jaccard_hfbf16"]).all(), (c["nucleus_jaccard_oracle"].min(), c["nucleus_jaccard_hfbf16"].min())
@@ -201,22 +213,22 @@ def test_oracle_vs_committed_hf_vectors(oracle, name):
     """The pin that does not need `transformers` at test time: HF-fp32 hidden states after 1 / 2 / 30 layers and
     post-CFG logits at steps 0, 1, 2 (the prefill's last row, two KV-cache decode steps), committed in hf_gate.npz by make_golden.py g4.
     The oracle's residual stream must be as close to them as HF's own bf16 run was when the fixture was made (x1.5), its logits within
-    LOGIT_TOL; and the committed 128-step evidence must itself satisfy the gate's criteria."""
-    import hf_gate as H
-    from chatterbox_vllm2_amd.weights import synthetic_cond_emb
+    LOGIT_TOL (the taps after 1 / 2 layers cost extra passes: short prompt only); and the committed 128-step evidence must itself satisfy
+    the gate's criteria."""
     z = np.load(os.path.join(G, "hf_gate.npz"))
-    vocab, prompt = _gate_case(name)
-    assert prompt == z[f"{name}_prompt"].tolist()
+    r = _gate_run(oracle, name)
+    assert r["prompt"] == z[f"{name}_prompt"].tolist()
     sel = [int(k) for k in z["sel_steps"]]
-    tens = H.gate_tensors(30, vocab)
-    ids, lg, fin, taps = H.oracle_teacher_forced(oracle, tens, 30, vocab, prompt, synthetic_cond_emb(1), max(sel) + 1, taps=(1, 2))
+    ids, lg, fin, taps = r["ids"], r["lg"], r["fin"], r["taps"]
     assert ids == z[f"{name}_ids"][:len(ids)].tolist()
     assert np.abs(lg[sel].numpy() - z[f"{name}_hf32_logits"]).max() <= LOGIT_TOL
-    nw = dict(tens)["tfmr.norm.weight"].float()
+    nw = dict(r["tens"])["tfmr.norm.weight"].float()
     f32 = fin.float(); post = f32 * torch.rsqrt(f32.pow(2).mean(-1, keepdim=True) + 1e-5) * nw
-    errs = [np.abs(taps[1][sel].float().numpy() - z[f"{name}_hf32_hidden_l1"]).mean(), np.abs(taps[2][sel].float().numpy() - z[f"{name}_hf32_hidden_l2"]).mean(),
-            np.abs(post[sel].numpy() - z[f"{name}_hf32_hidden_l30_postnorm"]).mean()]
-    for depth, e, e16 in zip((1, 2, 30), errs, z[f"{name}_hidden_err_hfbf16"]):
+    errs = {30: np.abs(post[sel].numpy() - z[f"{name}_hf32_hidden_l30_postnorm"]).mean()}
+    for depth in taps:
+        errs[depth] = np.abs(taps[depth][sel].float().numpy() - z[f"{name}_hf32_hidden_l{depth}"]).mean()
+    for depth, e in errs.items():
+        e16 = z[f"{name}_hidden_err_hfbf16"][{1: 0, 2: 1, 30: 2}[depth]]
         assert e <= 1.5 * e16 + 1e-5, f"hidden state after {depth} layers: oracle {e:.5f} vs HF bf16 {e16:.5f} (mean abs error against HF fp32)"
     # the committed evidence over all 128 steps
     n = int(z["n_steps"])
