@@ -208,8 +208,16 @@ __device__ __forceinline__ unsigned a_img_off(int row, int ch) {     // byte off
     else return (unsigned)(row * (KBS * 64) + ((ch ^ ((row >> 1) & (KBS * 4 - 1))) << 4));          // 128-byte rows: two rows per bank row
 }
 
+// EW: extra waves that sleep at the barrier and then share the epilogue.  The fold + epilogue of the 4-wave forms is a dependent chain of
+// ~300 vector instructions per thread (eight LDS reads, rstd, four SiLU-mul outputs with correctly rounded divisions) issued by ONE wave per
+// SIMD: 1.32 us of gate/up's 6.1 us, 0.52 of qkv's 3.6 (stamps, profiles/r03_gemm_clk_m64.txt).  With four more waves every thread
+// finishes two columns instead of four and two waves share each SIMD's issue slots.
+#ifndef T3_GEMM2_EW
+#define T3_GEMM2_EW 4
+#endif
+template <int NW> constexpr int gemm2_ew() { return NW == 4 ? T3_GEMM2_EW : 0; }
 template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
-__global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
+__global__ __launch_bounds__((NW + gemm2_ew<NW>()) * 64) void gemm2_kernel(GemmArgs a) {
     T3_G2STAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];      // [NW waves][MT][16 rows][KBS * 64 B] | NORM: float [NW][MT*16]
     static_assert(NT <= KBS && (KBS == 8 || KBS == 2) && (NW == 4 || NW == 16), "gemm2 shapes");
@@ -228,6 +236,8 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
         const int m = blockIdx.y * 16 + 4 * (l2 >> 4) + r, n = blockIdx.x * 16 + (l2 & 15);
         if (tid < 256 && m < a.M && n < a.N) hres = reinterpret_cast<const uint16_t*>(a.out)[(size_t)m * a.ldo + n];
     }
+    constexpr int EW = gemm2_ew<NW>();
+    if (EW == 0 || wave < NW) {          // the compute waves; the EW epilogue waves go straight to the barrier
     // ---- A: full row segments of this wave's K slice
     uint4_v ar[MT][KBS];
     const int rsub = lane / LPR, ch = lane % LPR;
@@ -313,31 +323,40 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
             if ((c >> 2) == q) rowsum[wave * (MT * 16) + i * 16 + c] = d;
         }
     }
+    }                                     // compute waves
     __syncthreads();
     T3_G2STAMP(4);
     auto part = [&](int w) { return reinterpret_cast<const float*>(lds2 + (size_t)w * ABYTES); };
 
     if constexpr (NW == 4) {
-        // four outputs (one row, four columns) per thread and step: 16-byte LDS reads, 8-byte stores
-        constexpr int NTO = (EPI == EPI_SILU) ? NT / 2 : NT, PIECES = MT * NTO * 64, PIT = (PIECES + 255) / 256;
+        // CW outputs (one row, CW columns) per thread and step: four (16-byte LDS reads, 8-byte stores) with the compute waves alone,
+        // two with the epilogue waves
+        constexpr int CW = EW ? 2 : 4, PPT = 16 / CW;                       // pieces per 16-column tile row
+        constexpr int NTO = (EPI == EPI_SILU) ? NT / 2 : NT, PIECES = MT * NTO * 16 * PPT, TH = (NW + EW) * 64, PIT = (PIECES + TH - 1) / TH;
 #pragma unroll
         for (int k = 0; k < PIT; ++k) {
-            const int p = tid + k * 256;
+            const int p = tid + k * TH;
             if (p >= PIECES) continue;
-            const int ito = p >> 6, r16 = (p >> 2) & 15, qq = p & 3;
+            const int ito = p / (16 * PPT), r16 = (p / PPT) & 15, qq = p % PPT;
             const int i = ito / NTO, to = ito % NTO;
             const int m = (blockIdx.y * MT + i) * 16 + r16;
             if (m >= a.M) continue;
             const int g = r16 >> 2, r = r16 & 3;
-            float v[EPI == EPI_SILU ? 2 : 1][4];
+            float v[EPI == EPI_SILU ? 2 : 1][CW];
 #pragma unroll
             for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u) {
                 const int it = i * NT + (EPI == EPI_SILU ? 2 * to + u : to);
-                const int o = (it * 4 + r) * 64 + 16 * g + 4 * qq;
-                const float4 s0 = *reinterpret_cast<const float4*>(part(0) + o), s1 = *reinterpret_cast<const float4*>(part(1) + o),
-                             s2 = *reinterpret_cast<const float4*>(part(2) + o), s3 = *reinterpret_cast<const float4*>(part(3) + o);
-                v[u][0] = ((s0.x + s1.x) + s2.x) + s3.x; v[u][1] = ((s0.y + s1.y) + s2.y) + s3.y;
-                v[u][2] = ((s0.z + s1.z) + s2.z) + s3.z; v[u][3] = ((s0.w + s1.w) + s2.w) + s3.w;
+                const int o = (it * 4 + r) * 64 + 16 * g + CW * qq;
+                if constexpr (CW == 4) {
+                    const float4 s0 = *reinterpret_cast<const float4*>(part(0) + o), s1 = *reinterpret_cast<const float4*>(part(1) + o),
+                                 s2 = *reinterpret_cast<const float4*>(part(2) + o), s3 = *reinterpret_cast<const float4*>(part(3) + o);
+                    v[u][0] = ((s0.x + s1.x) + s2.x) + s3.x; v[u][1] = ((s0.y + s1.y) + s2.y) + s3.y;
+                    v[u][2] = ((s0.z + s1.z) + s2.z) + s3.z; v[u][3] = ((s0.w + s1.w) + s2.w) + s3.w;
+                } else {
+                    const float2 s0 = *reinterpret_cast<const float2*>(part(0) + o), s1 = *reinterpret_cast<const float2*>(part(1) + o),
+                                 s2 = *reinterpret_cast<const float2*>(part(2) + o), s3 = *reinterpret_cast<const float2*>(part(3) + o);
+                    v[u][0] = ((s0.x + s1.x) + s2.x) + s3.x; v[u][1] = ((s0.y + s1.y) + s2.y) + s3.y;
+                }
             }
             if constexpr (NORM) {
                 const int rl = i * 16 + r16;
@@ -346,23 +365,25 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs a) {
 #pragma unroll
                 for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[u][e] = v[u][e] * rstd;
+                    for (int e = 0; e < CW; ++e) v[u][e] = v[u][e] * rstd;
             }
-            const int n = (blockIdx.x * NTO + to) * 16 + 4 * qq;
+            const int n = (blockIdx.x * NTO + to) * 16 + CW * qq;
             if (n >= a.N) continue;
             if constexpr (EPI == EPI_F32) {
                 float* op = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (n + e < a.N) op[e] = v[0][e];
+                for (int e = 0; e < CW; ++e) if (n + e < a.N) op[e] = v[0][e];
             } else {
-                uint32_t ob[4];
+                uint32_t ob[CW];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ob[e] = (EPI == EPI_SILU) ? silu_mul_bf(f2bf(v[0][e]), f2bf(v[EPI == EPI_SILU ? 1 : 0][e])) : f2bf(v[0][e]);
+                for (int e = 0; e < CW; ++e) ob[e] = (EPI == EPI_SILU) ? silu_mul_bf(f2bf(v[0][e]), f2bf(v[EPI == EPI_SILU ? 1 : 0][e])) : f2bf(v[0][e]);
                 uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
-                if (n + 3 < a.N || a.ldo >= ((a.N + 3) & ~3)) *reinterpret_cast<uint2*>(op) = make_uint2(ob[0] | (ob[1] << 16), ob[2] | (ob[3] << 16));
-                else {
+                if (n + CW - 1 < a.N || a.ldo >= ((a.N + CW - 1) & ~(CW - 1))) {
+                    if constexpr (CW == 4) *reinterpret_cast<uint2*>(op) = make_uint2(ob[0] | (ob[1] << 16), ob[2] | (ob[3] << 16));
+                    else *reinterpret_cast<uint32_t*>(op) = ob[0] | (ob[1] << 16);
+                } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (n + e < a.N) op[e] = (uint16_t)ob[e];
+                    for (int e = 0; e < CW; ++e) if (n + e < a.N) op[e] = (uint16_t)ob[e];
                 }
             }
         }
@@ -843,7 +864,7 @@ static hipError_t launch_gemm2_t(const GemmArgs* a, hipStream_t s) {
     const int ntiles = a->packed_tiles > 0 ? a->packed_tiles / (EPI == EPI_SILU ? 2 : 1) : (a->N + 15) / 16;
     const int gx = (EPI == EPI_SILU) ? (ntiles + NT / 2 - 1) / (NT / 2) : (ntiles + NT - 1) / NT;
     const int gy = ((a->M + 15) / 16 + MT - 1) / MT;
-    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NW * 64), lds, s, *a);
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3((NW + gemm2_ew<NW>()) * 64), lds, s, *a);
     return hipGetLastError();
 }
 // looped NORM form (>= 4 m-groups of 32 rows, no row gather): one workgroup per n-group, weights stationary in registers
