@@ -1989,8 +1989,16 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
 // Probability mass lives on integer weights w = floor(exp(l - max) * 2^32), so every sum is exact and
 // order-free; thresholds come from binary searches on the weight value (DESIGN.md "Sampler").
 // ------------------------------------------------------------------------------------------------
-constexpr int SPT = 33;                 // elements per thread in contiguous ownership: 256*33 >= 8194
-constexpr int SLOTS = 256 * SPT;
+// Waves per utterance.  With 4 waves (round 1-2) every SIMD of the CU ran ONE wave through ~3 000 dependent vector instructions (40 logits
+// of CFG / penalties / correctly rounded division per thread, then 33 exps): 10.8 + 4.2 us of a 29 us launch (tools/sampler_clk.py).
+// With 16 waves a thread owns 9 entries and four waves share a SIMD's issue slots.
+#ifndef T3_SAMPLER_WAVES
+#define T3_SAMPLER_WAVES 16
+#endif
+constexpr int SWV = T3_SAMPLER_WAVES, STH = SWV * 64;
+constexpr int SPT = (8194 + STH - 1) / STH;     // elements per thread in contiguous ownership: STH * SPT >= 8194 (33 at 4 waves, 9 at 16)
+constexpr int SLOTS = STH * SPT;
+constexpr int SSCR = 32;                        // scratch words behind the weights: [SWV] wave partials | [24] the drawn token
 
 // Wave-level reductions and scans on the DPP cross-lane path (a ds_bpermute butterfly costs ~0.2 us per level here;
 // the sampler is a chain of such reductions).  All operands are integers (or a float max), so order is immaterial.
@@ -2026,14 +2034,20 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
     __syncthreads();
-    return scr[0] + scr[1] + scr[2] + scr[3];
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < SWV; ++w) t += scr[w];
+    return t;
 }
 __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, unsigned long long* scr) {
     v = wave_max_u64(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
     __syncthreads();
-    return max_u64(max_u64(scr[0], scr[1]), max_u64(scr[2], scr[3]));
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < SWV; ++w) t = max_u64(t, scr[w]);
+    return t;
 }
 // max over finite-or-minus-infinity floats through the order-preserving integer key
 __device__ __forceinline__ float block_max_f32(float v, unsigned long long* scr) {
@@ -2043,16 +2057,18 @@ __device__ __forceinline__ float block_max_f32(float v, unsigned long long* scr)
     b = (b & 0x80000000u) ? (b & 0x7fffffffu) : ~b;
     return __uint_as_float(b);
 }
-// inclusive prefix sum over the 256 threads of the workgroup; *total = sum over all
+// inclusive prefix sum over the threads of the workgroup; *total = sum over all
 __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v, unsigned long long* scr, unsigned long long* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v = wave_scan_u64(v, lane);
     __syncthreads();
     if (lane == 63) scr[wave] = v;
     __syncthreads();
-    const unsigned long long s0 = scr[0], s1 = scr[1], s2 = scr[2], s3 = scr[3];
-    *total = s0 + s1 + s2 + s3;
-    return v + (wave >= 1 ? s0 : 0) + (wave >= 2 ? s1 : 0) + (wave >= 3 ? s2 : 0);
+    unsigned long long tot = 0, before = 0;
+#pragma unroll
+    for (int w = 0; w < SWV; ++w) { const unsigned long long sw_ = scr[w]; before += w < wave ? sw_ : 0; tot += sw_; }
+    *total = tot;
+    return v + before;
 }
 
 __device__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -2072,14 +2088,14 @@ __device__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 #else
 #define T3_CLK(i)
 #endif
-__global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
+__global__ __launch_bounds__(STH) void sampler_kernel(SampleArgs a) {
 #ifdef T3_SAMPLER_CLK
     unsigned long long clk[12] = {0};
 #endif
     T3_CLK(0);
-    extern __shared__ __attribute__((aligned(16))) unsigned long long sw[];   // [SLOTS] weights | [8] scratch | [256] partial sums
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sw[];   // [SLOTS] weights | [SSCR] scratch | [256] histogram copies
     unsigned long long* scr = sw + SLOTS;
-    unsigned long long* psum = scr + 8;
+    unsigned long long* psum = scr + SSCR;
     const int tid = threadIdx.x, u = blockIdx.x;
     const int slot = a.sel[u].x;
     const uint32_t step = (uint32_t)a.sel[u].y;
@@ -2094,23 +2110,23 @@ __global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
     const bool greedy = sp.temperature < 1e-5f;
     float mx = -INFINITY;
     unsigned long long best = 0;
-    constexpr int NVEC = VPAD / 8, VIT = (NVEC + 255) / 256;
+    constexpr int NVEC = VPAD / 8, VIT = (NVEC + STH - 1) / STH;
     static_assert(VPAD % 8 == 0 && SLOTS >= VPAD, "sampler vector layout");
     uint4 c4[VIT], u4[VIT], n4[VIT];
 #pragma unroll
     for (int k = 0; k < VIT; ++k) {
-        const int vi = tid + 256 * k;
+        const int vi = tid + STH * k;
         if (vi < NVEC) {
             c4[k] = reinterpret_cast<const uint4*>(lc)[vi];
             u4[k] = reinterpret_cast<const uint4*>(lu)[vi];
             n4[k] = reinterpret_cast<const uint4*>(counts)[vi];
         }
     }
-    for (int v = VPAD + tid; v < SLOTS; v += 256) xs[2 * v] = -INFINITY;
+    for (int v = VPAD + tid; v < SLOTS; v += STH) xs[2 * v] = -INFINITY;
     T3_CLK(1);
 #pragma unroll
     for (int k = 0; k < VIT; ++k) {
-        const int vi = tid + 256 * k;
+        const int vi = tid + STH * k;
         if (vi >= NVEC) continue;
         const uint32_t cw[4] = {c4[k].x, c4[k].y, c4[k].z, c4[k].w}, uw[4] = {u4[k].x, u4[k].y, u4[k].z, u4[k].w},
                        nw[4] = {n4[k].x, n4[k].y, n4[k].z, n4[k].w};
@@ -2153,9 +2169,9 @@ __global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
     } else {
         mx = block_max_f32(mx, scr);
         // ---- weights (block_max above is the barrier between writing xs and overwriting it slot by slot)
-#pragma unroll 11
+#pragma unroll
         for (int k = 0; k < SPT; ++k) {
-            const int v = tid + 256 * k;
+            const int v = tid + STH * k;
             const float x = xs[2 * v];
             unsigned long long w = 0;
             if (v < V) w = (unsigned long long)(t3_expf(x - mx) * 4294967296.0f);
@@ -2202,25 +2218,30 @@ __global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
             // round; per round an LDS histogram of masses (exact integer sums, so order-free) and a 64-bin
             // wave scan that every wave repeats for itself.
             T3_CLK(5);
-            unsigned long long* hist = psum;                 // [64]
+            // The histogram is kept in HC copies, one per lane group (lane & (HC - 1)): the masses of a round fall into a handful of the 64
+            // bins (a softmax's weights share few octaves), and 64-bit LDS atomics of one wave instruction onto the same bin serialise.  The sums
+            // are exact integers, so the copies add up to the same histogram in any order.
+            constexpr int HC = 4;
+            unsigned long long* hist = psum;                 // [HC][64]
             const int lane = tid & 63;
+            unsigned long long* myhist = hist + (lane & (HC - 1)) * 64;
             unsigned long long lo = wmax, base = 0, prefix = 0;
             int nb = -1;                                     // bits of the value still undetermined; -1: octave round
             for (;;) {
                 __syncthreads();
-                if (tid < 64) hist[tid] = 0;
+                if (tid < HC * 64) hist[tid] = 0;
                 __syncthreads();
                 if (nb < 0) {
 #pragma unroll
-                    for (int i = 0; i < SPT; ++i) if (wr[i]) atomicAdd(&hist[64 - __clzll((long long)wr[i])], wr[i]);
+                    for (int i = 0; i < SPT; ++i) if (wr[i]) atomicAdd(&myhist[64 - __clzll((long long)wr[i])], wr[i]);
                 } else {
                     const int shift = nb > 6 ? nb - 6 : 0;
                     const unsigned long long msk = (1ull << (nb - shift)) - 1;
 #pragma unroll
-                    for (int i = 0; i < SPT; ++i) if ((wr[i] >> nb) == prefix) atomicAdd(&hist[(wr[i] >> shift) & msk], wr[i]);
+                    for (int i = 0; i < SPT; ++i) if ((wr[i] >> nb) == prefix) atomicAdd(&myhist[(wr[i] >> shift) & msk], wr[i]);
                 }
                 __syncthreads();
-                const unsigned long long own = hist[lane];
+                const unsigned long long own = (hist[lane] + hist[64 + lane]) + (hist[128 + lane] + hist[192 + lane]);
                 const unsigned long long c = wave_scan_u64(own, lane);      // inclusive scan over the 64 bins
                 const unsigned long long over = __ballot(base + c > Tm);
                 if (!over) break;                            // only in the octave round, when Tm == W: lo = wmax
@@ -2262,10 +2283,10 @@ __global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
         philox4x32_10(step, (uint32_t)sp.uid, (uint32_t)(sp.uid >> 32), 0u, (uint32_t)sp.seed, (uint32_t)(sp.seed >> 32), rnd);
         const unsigned long long uu = ((unsigned long long)rnd[1] << 32) | rnd[0];
         const unsigned long long target = __umul64hi(uu, Wk);
-        int* tokp = reinterpret_cast<int*>(scr + 4);
+        int* tokp = reinterpret_cast<int*>(scr + 24);
         // No thread owns the target when there is no mass at all (NaN logits: a checkpoint or conditioning with NaN / Inf makes
         // every weight 0): the draw then falls back to the stop id instead of whatever the LDS word held.  The write is ordered
-        // before the owner's by the barriers inside block_scan_u64 above (scr + 4 is not one of its four words).
+        // before the owner's by the barriers inside block_scan_u64 above (scr + 24 is not one of its SWV words).
         if (Wk == 0 && tid == 0) *tokp = (sp.stop_token >= 0 && sp.stop_token < V) ? sp.stop_token : 0;
         if (mine > 0 && target >= excl && target < excl + mine) {
             unsigned long long cum = excl; int found = -1;      // first entry whose running mass passes the target
@@ -2291,7 +2312,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SampleArgs a) {
 hipError_t prepare_kernels() {
     static bool done[MAX_DEVICES] = {};
     if (done[cur_device()]) return hipSuccess;
-    const size_t lds = (size_t)(SLOTS + 8 + 256) * sizeof(unsigned long long);
+    const size_t lds = (size_t)(SLOTS + SSCR + 256) * sizeof(unsigned long long);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) e = prepare_gemm2();
     if (e == hipSuccess) done[cur_device()] = true;
@@ -2299,10 +2320,10 @@ hipError_t prepare_kernels() {
 }
 hipError_t launch_sampler(const SampleArgs& a, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
-    const size_t lds = (size_t)(SLOTS + 8 + 256) * sizeof(unsigned long long);
+    const size_t lds = (size_t)(SLOTS + SSCR + 256) * sizeof(unsigned long long);
     hipError_t e = prepare_kernels();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sampler_kernel, dim3(a.n), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(sampler_kernel, dim3(a.n), dim3(STH), lds, s, a);
     return hipGetLastError();
 }
 
