@@ -876,6 +876,7 @@ static int complete_step(T3Engine* e, T3Engine::Step& st, T3StepResult* res) {
                 if (res->n_finished < 64) res->finished_ids[res->n_finished] = r.id;
                 res->n_finished++;
                 e->finished_q.push_back(r.id);
+                if (e->finished_q.size() > (size_t)(4 * e->cfg.max_seqs + 4096)) e->finished_q.pop_front();     // a caller that never pops (LLM.generate reads outputs by id) must not grow it
                 if (r.n_sched > (int)r.out.size()) r.zombie = true;     // the step running ahead still uses its slot and KV blocks
                 else release_slot(e, r);
             }

@@ -124,7 +124,8 @@ int t3_run_steps(T3Handle h, int32_t n, int32_t* done);
 int t3_num_unfinished(T3Handle h);
 /* Ids of the requests that finished since the previous call (any of t3_step / t3_run_steps / t3_run_until_done), oldest first:
  * up to `cap` of them are written to ids and leave the queue.  Returns how many were written (a step of 128 utterances can retire
- * more than the 64 that fit T3StepResult), or a negative T3_E_* code.  vLLM hands finished RequestOutputs back from every
+ * more than the 64 that fit T3StepResult), or a negative T3_E_* code.  The queue keeps the most recent 4 * max_seqs + 4096 ids: a
+ * serving loop pops after every step; a caller that reads outputs by request id need not pop at all.  vLLM hands finished RequestOutputs back from every
  * engine step (LLM.generate collects them, tts.py:445-465); this is that stream of ids. */
 int t3_pop_finished(T3Handle h, int64_t* ids, int32_t cap);
 /* ids: offset-space token ids (>= 2500), the stop id included when hit.
