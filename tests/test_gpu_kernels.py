@@ -222,6 +222,19 @@ def test_fused_decode_attention_bit_exact(E, oracle, rows, waves):
         assert_bit_equal(got, want, f"fused decode attention rows={rows} waves={waves} launch {j}")
 
 
+def test_fused_decode_attention_long_contexts(E, oracle):
+    """max_model_len goes up to 8192 (t3_create): the fused decode kernel at contexts of 2 049 .. 8 000 tokens (32-125 chunks per row, 8-31 KV
+    blocks per stream, 8 and 4 waves), two launches each."""
+    max_pos = 8192
+    ctx_qkv = rand_bf16(2, 8000, 3072, seed=91)
+    for rows, waves, ctx in ((2, 8, [8000, 4097]), (3, 4, [2049, 4095, 6400])):
+        new_qkv = rand_bf16(2, rows, 3072, seed=92 + rows)
+        got, kv_got = E.k_decode_attention(ctx_qkv, new_qkv, ctx, max_pos, waves)
+        want, kv_want = _oracle_decode_attention(oracle, ctx_qkv, new_qkv, ctx, max_pos)
+        assert_bit_equal(kv_got, kv_want, f"newest K / V at contexts {ctx}")
+        assert_bit_equal(got, want, f"fused decode attention at contexts {ctx}")
+
+
 def test_fused_decode_attention_256_rows(E, oracle):
     """A 128-utterance decode step (C4): 256 rows in one launch, contexts spread over the 13 boundary cases, as the engine picks the waves."""
     rows, max_pos = 256, 1001
