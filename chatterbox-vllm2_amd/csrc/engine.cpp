@@ -77,8 +77,7 @@ struct T3Engine {
     int n_groups = 1;
     int row_stride = 0;        // int32 words per row record
     bool fuse_rope = true;
-    bool fuse_qkv_small = false;      // T3_FUSE_QKV_SMALL=1: decode steps of 2 / 4 rows run the qkv projection + attention of a layer as one launch
-                                      // (bit-exact; measured SLOWER: 16 workgroups cannot pull the 6.3 MB of qkv weights fast enough)
+    bool qkv_in_attn = false;         // T3_QKV_IN_ATTN=1: decode-only steps run the qkv projection inside the attention launch (units + flags, t3_kernels.hip)
 
     // weights (device)
     std::vector<LayerW> layers;
@@ -100,6 +99,7 @@ struct T3Engine {
     struct Group {
         hipStream_t stream = nullptr;
         uint16_t *h = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *act = nullptr, *logits = nullptr;
+        unsigned* sync = nullptr; int sync_stride = 0;      // per layer: ticket / flags of the qkv-in-attention launch (zeroed by the step's embed kernel)
         float* rstd = nullptr;     // row statistic of the prefill-sized NORM GEMMs
         char *h_meta[2] = {nullptr, nullptr}, *d_meta = nullptr;     // host staging is double-buffered: step N+1 is built while N runs
         size_t meta_bytes = 0, meta_rows_off = 0;
@@ -209,7 +209,7 @@ extern "C" int t3_create(const T3EngineConfig* cfg, T3Handle* out) {
         e->n_groups = std::max(1, std::min(g, std::min(8, cfg->max_seqs)));
         e->groups.resize(e->n_groups);
         if (const char* ev = getenv("T3_FUSE_ROPE")) e->fuse_rope = atoi(ev) != 0;
-        if (const char* ev = getenv("T3_FUSE_QKV_SMALL")) e->fuse_qkv_small = atoi(ev) != 0;
+        if (const char* ev = getenv("T3_QKV_IN_ATTN")) e->qkv_in_attn = atoi(ev) != 0;
         if (const char* ev = getenv("T3_RUN_AHEAD")) e->run_ahead = atoi(ev) != 0;
         e->antiphase = e->n_groups == 2;
         if (const char* ev = getenv("T3_ANTIPHASE")) e->antiphase = atoi(ev) != 0 && e->n_groups == 2;
@@ -236,6 +236,7 @@ extern "C" int t3_destroy(T3Handle e) {
     for (auto& g : e->groups) {
         if (g.stream) (void)hipStreamSynchronize(g.stream);
         for (auto& kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
+        free_dev(g.sync);
         free_dev(g.h); free_dev(g.qkv); free_dev(g.qrot); free_dev(g.att); free_dev(g.act); free_dev(g.logits); free_dev(g.rstd);
         free_dev(g.d_meta); free_dev(g.dm.out_tok);
         for (int b = 0; b < 2; ++b) {
@@ -407,6 +408,8 @@ extern "C" int t3_finalize_weights(T3Handle e) {
         if ((rc = dalloc(e, &g.act, R * F, true))) return rc;
         if ((rc = dalloc(e, &g.logits, 2 * Sg * VPAD, true))) return rc;
         if ((rc = dalloc(e, &g.rstd, R, true))) return rc;
+        g.sync_stride = (qkv_in_attention_sync_words((int)(2 * Sg)) + 15) & ~15;
+        if ((rc = dalloc(e, &g.sync, (size_t)e->cfg.n_layers * g.sync_stride, true))) return rc;
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
         const size_t o_selr = carve(2 * Sg * 4), o_sel = carve(Sg * 16), o_rows = carve(R * (size_t)e->row_stride * 4);
@@ -553,9 +556,14 @@ struct Prof {
 
 // One group's kernel sequence for one step, in phases (eager, or recorded into a hipGraph by the caller): embed | per layer: qkv,
 // attention (RoPE / KV write fused for decode rows), o + gate/up + down | head + sampler.
+static bool step_fuses_qkv(const T3Engine* e, const T3Engine::StepRec& sr) {
+    return e->qkv_in_attn && e->fuse_rope && sr.n_prefill_rows == 0 && sr.M >= 2 && sr.M <= 2 * ((e->cfg.max_seqs + e->n_groups - 1) / e->n_groups) &&
+           qkv_in_attention_fits(sr.M, (e->cfg.max_model_len + CHUNK - 1) / CHUNK);
+}
 static int launch_embed_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, hipStream_t s) {
     Prof p(e, K_EMBED, s);
     EmbedArgs ea{g.dm.rows, e->row_stride, e->d_cond, e->text_emb, e->text_pos, e->speech_emb, e->speech_pos, g.h, sr.M, g.dm.out_tok};
+    if (step_fuses_qkv(e, sr)) { ea.zero_words = g.sync; ea.n_zero = e->cfg.n_layers * g.sync_stride; }
     HIP_TRY(launch_embed(ea, s));
     if (e->d_dbg_emb) HIP_TRY(hipMemcpyAsync(e->d_dbg_emb, g.h, (size_t)sr.M * D * 2, hipMemcpyDeviceToDevice, s));
     return T3_OK;
@@ -593,16 +601,13 @@ static int launch_attention_phase(T3Engine* e, T3Engine::Group& g, const T3Engin
     }
     return T3_OK;
 }
-// decode steps of one or two utterances: the qkv projection and the fused attention of a layer as ONE launch (a workgroup per head)
-static bool small_step_fuses(const T3Engine* e, const T3Engine::StepRec& sr) {
-    return e->fuse_qkv_small && e->fuse_rope && sr.n_prefill_rows == 0 && qkv_attention_small_fits(sr.M, (e->cfg.max_model_len + CHUNK - 1) / CHUNK);
-}
+// decode-only steps: the qkv projection runs INSIDE the attention launch (units taken by ticket, flags; qkv_in_attention_kernel)
 static int launch_qkv_attention_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int L, hipStream_t s) {
     const size_t layer_elems = (size_t)e->n_blocks * KV_BLOCK_ELEMS;
     uint16_t* kvL = e->kv + (size_t)L * layer_elems;
     Prof p(e, K_ATTN, s);
     AttnArgs aa{nullptr, kvL, g.dm.rows, e->row_stride, g.att, sr.M, (e->cfg.max_model_len + CHUNK - 1) / CHUNK, g.qkv, kvL, e->cos_t, e->sin_t};
-    HIP_TRY(launch_qkv_attention_small(g.h, (const uint4*)e->layers[L].qkv, aa, s));
+    HIP_TRY(launch_qkv_in_attention(g.h, (const uint4*)e->layers[L].qkv, g.qkv, g.sync + (size_t)L * g.sync_stride, aa, s));
     return T3_OK;
 }
 static int launch_mlp_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int L, hipStream_t s) {
@@ -624,9 +629,9 @@ static int launch_sample_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::
 static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, hipStream_t s) {
     int rc;
     if ((rc = launch_embed_phase(e, g, sr, s))) return rc;
-    const bool fused_small = small_step_fuses(e, sr);
+    const bool fused_qkv = step_fuses_qkv(e, sr);
     for (int L = 0; L < e->cfg.n_layers; ++L) {
-        if (fused_small) {
+        if (fused_qkv) {
             if ((rc = launch_qkv_attention_phase(e, g, sr, L, s))) return rc;
         } else {
             if ((rc = launch_qkv_phase(e, g, sr, L, s))) return rc;

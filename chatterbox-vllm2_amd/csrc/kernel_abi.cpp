@@ -157,7 +157,7 @@ static int decode_attention_impl(const void* ctx_qkv, int32_t n_content, int32_t
     const void* new_qkv = new_rows;
     if (!ctx_qkv || !new_qkv || !ctx || !out || rows <= 0 || steps <= 0 || n_content <= 0 || content_rows <= 0 || max_pos <= 0 ||
         (waves != 0 && waves != 4 && waves != 8)) return T3_E_INVALID;
-    if (wqkv_packed && !qkv_attention_small_fits(rows, (max_pos + CHUNK - 1) / CHUNK)) return T3_E_INVALID;
+    if (wqkv_packed && !qkv_in_attention_fits(rows, (max_pos + CHUNK - 1) / CHUNK)) return T3_E_INVALID;
     for (int r = 0; r < rows; ++r)
         if (ctx[r] < 1 || ctx[r] - 1 > content_rows || ctx[r] - 1 + steps > max_pos) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
@@ -173,8 +173,12 @@ static int decode_attention_impl(const void* ctx_qkv, int32_t n_content, int32_t
     rope_tables(max_pos, c.data(), s.data());
     const int stride = row_stride_words(max_blocks);
     DevBuf dctx, dnew, dc, ds, dq, dkv, dout, dkvn, drec_fill, drec;
-    DevBuf dw;
-    if (wqkv_packed) K_TRY(dw.from(wqkv_packed, (size_t)QKV * D * 2));
+    DevBuf dw, dqkv_out, dsync;
+    const int sync_words = (qkv_in_attention_sync_words(rows) + 15) & ~15;
+    if (wqkv_packed) {
+        K_TRY(dw.from(wqkv_packed, (size_t)QKV * D * 2));
+        K_TRY(dqkv_out.alloc((size_t)rows * QKV * 2, true)); K_TRY(dsync.alloc((size_t)sync_words * 4, true));
+    }
     K_TRY(dctx.from(ctx_qkv, (size_t)n_content * content_rows * QKV * 2)); K_TRY(dnew.from(new_qkv, (size_t)steps * rows * (wqkv_packed ? D : QKV) * 2));
     K_TRY(dc.from(c.data(), c.size() * 4)); K_TRY(ds.from(s.data(), s.size() * 4));
     K_TRY(dq.alloc((size_t)content_rows * D * 2));                     // rotated q of the fill rows: not used
@@ -211,8 +215,15 @@ static int decode_attention_impl(const void* ctx_qkv, int32_t n_content, int32_t
         AttnArgs aa{nullptr, dkv.as<uint16_t>(), drec.as<int>(), stride, dout.as<uint16_t>() + (size_t)st * rows * D, rows, (max_pos + CHUNK - 1) / CHUNK,
                     dnew.as<uint16_t>() + (size_t)st * rows * QKV, dkv.as<uint16_t>(), dc.as<float>(), ds.as<float>()};
         aa.force_waves = waves;
-        if (wqkv_packed) K_TRY(launch_qkv_attention_small(dnew.as<uint16_t>() + (size_t)st * rows * D, dw.as<uint4>(), aa, nullptr));
-        else K_TRY(launch_attention(aa, nullptr));
+        if (wqkv_packed) {
+            K_TRY(hipMemset(dsync.p, 0, (size_t)sync_words * 4));      // every polled word is zero at launch (the engine's embed kernel does this per step)
+            aa.qkv = dqkv_out.as<uint16_t>();
+            K_TRY(launch_qkv_in_attention(dnew.as<uint16_t>() + (size_t)st * rows * D, dw.as<uint4>(), dqkv_out.as<uint16_t>(), dsync.as<unsigned>(), aa, nullptr));
+            K_TRY(hipDeviceSynchronize());
+            unsigned gave_up = 0;
+            K_TRY(hipMemcpy(&gave_up, dsync.as<unsigned>() + 1, 4, hipMemcpyDeviceToHost));
+            if (gave_up) return T3_E_DEVICE;                            // a workgroup stopped waiting for a projection unit
+        } else K_TRY(launch_attention(aa, nullptr));
         K_TRY(launch_kv_gather(dkv.as<uint16_t>(), drec.as<int>(), stride, rows, dkvn.as<uint16_t>() + (size_t)st * rows * 2 * D, nullptr));
         K_TRY(hipDeviceSynchronize());
     }
@@ -226,7 +237,7 @@ extern "C" int t3k_decode_attention(const void* ctx_qkv, int32_t n_content, int3
     return decode_attention_impl(ctx_qkv, n_content, content_rows, new_qkv, nullptr, ctx, rows, steps, max_pos, waves, out, kv_new);
 }
 
-/* The one-launch qkv projection + fused decode attention of small decode steps (2 or 4 rows): as t3k_decode_attention, but launch s takes the
+/* The qkv projection inside the fused decode attention launch (qkv_in_attention_kernel): as t3k_decode_attention, but launch s takes the
  * residual rows h[s][r] ([steps][rows][1024] bf16) and projects them itself: q | k | v = bf16(rstd * GEMM(h, bf16(Wqkv * ln_w))). */
 extern "C" int t3k_qkv_decode_attention(const void* ctx_qkv, int32_t n_content, int32_t content_rows, const void* h_rows, const void* ln_w, const void* wqkv,
                                         const int32_t* ctx, int32_t rows, int32_t steps, int32_t max_pos, void* out, void* kv_new) {

@@ -63,6 +63,7 @@ struct EmbedArgs {
     uint16_t* h;               // [rows][1024]
     int rows;
     const int* prev_tok;       // the sampler's output array of the previous step (EMB_SPEECH_PREV)
+    unsigned* zero_words = nullptr; int n_zero = 0;     // words this launch sets to 0 (the step's hand-off state), nullable
 };
 enum EmbedKind { EMB_COND = 0 /*a=slot,b=idx*/, EMB_TEXT = 1 /*a=id,b=pos*/, EMB_ZERO = 2, EMB_SPEECH = 3 /*a=id,b=pos*/,
                  EMB_SPEECH_PREV = 4 /*a=index into prev_tok,b=pos*/ };
@@ -95,11 +96,12 @@ struct AttnArgs {
     int force_waves = 0;       // 4 / 8: waves per (row, head) workgroup of the per-row kernel (0: by row count; parity tests check both)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
-// Small decode steps (2 or 4 rows = 1 or 2 utterances): the qkv projection (RMSNorm folded) and the fused decode attention of a layer in ONE
-// launch, a workgroup of 16 waves per head.  x: the residual stream [rows][1024]; wqkv: the layer's packed, norm-folded qkv matrix; a: the
-// fused-form attention arguments (a.qkv is ignored: q / k / v never leave the workgroup).  Same numbers as gemm2_kernel + attention_kernel.
-bool qkv_attention_small_fits(int rows, int max_chunks);
-hipError_t launch_qkv_attention_small(const uint16_t* x, const uint4* wqkv, const AttnArgs& a, hipStream_t s);
+// The qkv projection inside the fused decode attention launch (any decode row count >= 2): x = residual rows [rows][1024], wqkv = the layer's
+// packed norm-folded matrix, qkv = the [rows][3072] buffer the units publish into, sync = qkv_in_attention_sync_words(rows) uint32 words that
+// must be ZERO at launch (word 1 comes back non-zero if a workgroup gave up waiting), a = the fused-form attention arguments.
+int qkv_in_attention_sync_words(int rows);
+bool qkv_in_attention_fits(int rows, int max_chunks);
+hipError_t launch_qkv_in_attention(const uint16_t* x, const uint4* wqkv, uint16_t* qkv, unsigned* sync, const AttnArgs& a, hipStream_t s);
 // parity hook: K (as stored, i.e. rotated) and V of every row's (stream, position) read back from the paged pool -> out [rows][2][1024]
 hipError_t launch_kv_gather(const uint16_t* kv_layer, const int* rowrec, int row_stride, int rows, uint16_t* out, hipStream_t s);
 

@@ -1077,6 +1077,8 @@ __device__ __forceinline__ uint4 add_bf8(const uint4& a, const uint4& b) {
     return o;
 }
 __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
+    // the first kernel of a step also zeroes the step's hand-off words (tickets and flags of the qkv-in-attention launches)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n_zero; i += gridDim.x * 256) a.zero_words[i] = 0u;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
     const int* rec = a.rowrec + (size_t)row * a.row_stride;
@@ -1562,89 +1564,57 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
     T3_ASTAMP(5);
 }
 // ------------------------------------------------------------------------------------------------
-// Small decode steps (R = 2 or 4 rows: one or two utterances, the reference server's own regime): qkv projection + fused decode
-// attention of a layer in ONE launch.  At these sizes a step is a chain of ~155 launches of 3-8 us each, and the qkv GEMM and the
-// attention are the one pair of neighbours whose seam is not all-to-all: head h's attention needs only head h's 192 columns of qkv.
-// One workgroup of 16 waves per head:
-//   phase 1 (GEMM, the numbers of gemm2_kernel's NORM form): wave = (K segment s = wave & 3, tile group g = wave >> 2); a wave folds its
-//     256-wide segment of 3 of the head's 12 n-tiles (q 0-3, k 4-7, v 8-11) with one MFMA chain per tile from +0 in ascending k; the
-//     segments of a tile fold ((s0 + s1) + s2) + s3 through LDS; row statistic from the MFMA diagonal (waves g = 0), rstd in the epilogue;
-//     q / k / v of the R rows stay in LDS as bf16.
-//   phase 2 (attention, the numbers of attention_kernel<16 / R, nt, FUSE>): 16 / R waves per row take the row's chunks round-robin; RoPE
-//     of q / k, paged write of the newest K / V, scores and P.V on the matrix cores, per-chunk partials in LDS, ascending-chunk fold.
-// The waves request their first K/V tile as soon as their weight registers are free, before the cross-segment fold: the tile's HBM round
-// trip runs under the fold and the barriers, and no kernel boundary sits between the projection and the attention.
-// MEASURED (round 3, B = 1, max_model_len 400): bit-exact with the two launches and SLOWER -- 19.8 us per evented launch against 7.4 + 10.1,
-// 1.010 against 0.839 ms per step (990 against 1 193 tok/s; B = 2: 1 760 against 2 354).  A workgroup per head is 16 CUs for 6.3 MB of
-// weights, 384 KB each, and one CU takes in ~50 GB/s: the projection alone lasts ~8 us there, against ~3.3 us spread over 192 CUs.  The
-// engine therefore keeps the two launches (T3_FUSE_QKV_SMALL=1 selects this kernel); its parity cases stay (t3k_qkv_decode_attention).
+// The qkv projection INSIDE the fused decode attention launch (any decode row count).  The attention of (row, head) needs only head h's
+// 192 qkv columns of row's m-tile: that seam is 3 producers -> 1 consumer, not all-to-all, and an attention launch spends its first
+// ~10 us waiting for its first K/V tiles anyway.  So the launch is the attention grid (16 heads x rows workgroups), and the projection is
+// cut into units (m-tile of 16 rows, head, q | k | v) = 4 n-tiles x K 1024, the shape of gemm2_kernel<1, 4, BF16, 4 waves>; the first
+// workgroups (4-wave groups) to ARRIVE each take one unit by a ticket (a workgroup that holds a ticket is running and needs nothing from
+// anyone, so a unit cannot wait for a workgroup that is not resident), compute it with the MFMA chains / fold order / rstd epilogue of
+// gemm2_kernel, publish the 16 x 64 bf16 outputs write-through (sc1), drain, and raise the unit's flag; every workgroup then polls the
+// three flags of its (m-tile, head), reads its q / k / v pieces with sc1 loads (its L1 may hold the previous layer's lines of that
+// buffer) and runs attention_kernel's fused body unchanged.  Hand-off recipe: cdna_hip_programming.md Guideline 16 (R1); every polled
+// word is zeroed before every launch (embed_kernel does it in the engine); the poll is bounded and leaves a code in sync[1].
 // ------------------------------------------------------------------------------------------------
-struct QkvAttnArgs { const uint16_t* x; const uint4* wqkv; AttnArgs a; };
-constexpr int QA_PART_FLOATS = 12 * 4 * 4 * 64;           // [tile 12][segment 4][reg 4][lane 64] fp32 partials of the GEMM phase
-constexpr size_t qkv_attn_lds_floats(int R, int max_chunks) {
-    const size_t attn = (size_t)R * 66 * max_chunks + 16 * (96 + 12 * 64);      // per row m | l | o partials; per wave scores / probabilities / newest k, v
-    const size_t gemm = QA_PART_FLOATS + 4 * 16;                                 // partials + row statistic; aliased by the attention regions
-    return (attn > gemm ? attn : gemm) + (size_t)R * 96 + 4;                     // + q / k / v rows (bf16 [R][192]) + rstd pad
-}
-template <int R>
-__global__ __launch_bounds__(1024) void qkv_attention_kernel(QkvAttnArgs p) {
-    static_assert(R == 2 || R == 4, "one or two utterances");
-    constexpr int WPR = 16 / R;                              // waves per row in the attention phase
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+struct QkvInAttnArgs { const uint16_t* x; const uint4* wqkv; uint16_t* qkv; unsigned* sync; AttnArgs a; };
+constexpr int QIA_FLAGS = 16;                               // sync words: [0] ticket counter, [1] give-up code, [QIA_FLAGS + u] flag of unit u
+constexpr int QIA_GROUP_FLOATS = 4 * 4 * 4 * 64 + 64;       // a producing group's LDS: partials [tile 4][segment 4][reg 4][lane 64] + row statistic [4][16]
+inline int qia_units(int rows) { return (rows + 15) / 16 * 48; }
+inline size_t qia_lds_floats(int nw, int max_chunks) { return (size_t)max_chunks * 66 + (size_t)nw * (96 + 12 * 64) + (size_t)(nw / 4) * QIA_GROUP_FLOATS + 4; }
+typedef __attribute__((address_space(1))) unsigned gu32_t;
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+typedef __attribute__((address_space(1))) unsigned short gu16_t;
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void qkv_in_attention_kernel(QkvInAttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float part[];
     const AttnArgs& a = p.a;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform values stay in scalar registers
+    float* pm = part; float* pl = part + a.max_chunks; float* po = part + 2 * a.max_chunks;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* sbuf = part + 66 * a.max_chunks + wave * 96;
+    uint32_t* stash = reinterpret_cast<uint32_t*>(part + 66 * a.max_chunks + NW * 96) + wave * (12 * 64) + lane;
+    uint16_t* pbuf = reinterpret_cast<uint16_t*>(sbuf + 64);
+    const int grp = wave >> 2, sseg = wave & 3;             // 4-wave group (one per workgroup at NW = 4), K segment of the wave in a unit
+    float* gpart = part + 66 * a.max_chunks + NW * (96 + 12 * 64) + grp * QIA_GROUP_FLOATS;
+    float* growsum = gpart + 4 * 4 * 4 * 64;
+    int* tk = reinterpret_cast<int*>(part + 66 * a.max_chunks + NW * (96 + 12 * 64) + (NW / 4) * QIA_GROUP_FLOATS);
+    const int h = blockIdx.x, row = blockIdx.y;
     const int col = lane & 15, kg = lane >> 4;
-    const int h = blockIdx.x;
-    const size_t big = qkv_attn_lds_floats(R, a.max_chunks) - (size_t)R * 96 - 4;
-    uint16_t* qkv_s = reinterpret_cast<uint16_t*>(lds + big);          // [R][192] bf16: q | k | v of this head, pre-RoPE
-    float* part = lds;                                                 // GEMM phase
-    float* rowsum = lds + QA_PART_FLOATS;                              // [4 segments][16 rows]
-
-    // ---------------- phase 1: this head's 192 columns of the qkv projection
-    {
-        const int sseg = wave & 3, g = wave >> 2;
-        const int m = col < R ? col : R - 1;                           // padded rows re-read the last row; their outputs are dropped
-        const uint4* xp = reinterpret_cast<const uint4*>(p.x + (size_t)m * D + sseg * 256 + kg * 8);
-        uint4 af[8];
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb) af[kb] = xp[kb * 4];
-        f32x4 acc[3], ss = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int j = 3 * g + t, nt = (j >> 2) * 64 + h * 4 + (j & 3);             // packed n-tile of the [3072][1024] matrix: q rows 0.., k rows 1024.., v rows 2048..
-            const uint4* wp = p.wqkv + ((size_t)nt * 32 + sseg * 8) * 64 + lane;
-            uint4 w[8];
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) w[kb] = ld_nt(wp + kb * 64);
-            acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[kb]), as_frag(w[kb]), acc[t], 0, 0, 0);
-        }
-        if (g == 0) {
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) ss = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[kb]), as_frag(af[kb]), ss, 0, 0, 0);   // diagonal = sum of squares of the segment
-            const int r = col & 3;
-            const float d = r == 0 ? ss[0] : r == 1 ? ss[1] : r == 2 ? ss[2] : ss[3];
-            if ((col >> 2) == kg) rowsum[sseg * 16 + col] = d;
-        }
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part[(((3 * g + t) * 4 + sseg) * 4 + r) * 64 + lane] = acc[t][r];
-    }
-    // ---------------- attention set-up that does not need q / k / v: the wave's row, its chunks, its first tile (in flight across the fold)
-    const int row = wave / WPR, w = wave % WPR;
+    // ---- ticket: which unit, if any, this 4-wave group computes
+    if (sseg == 0 && lane == 0) tk[grp] = (int)atomicAdd(p.sync, 1u);
     const int* rec = a.rowrec + (size_t)row * a.row_stride;
     const int L = rec[1] + 1;
     const int nc = (L + CHUNK - 1) / CHUNK;
     const int* bt = rec + ROW_HDR;
     constexpr int CPB = KV_BLOCK / CHUNK;
+    __syncthreads();
+    const int unit = __builtin_amdgcn_readfirstlane(tk[grp]);
+    const bool producer = unit < ((a.rows + 15) >> 4) * 48;
+
     uint4 kf[8], vf[8];
     auto load_tiles = [&](int c) {
         const int blk = bt[c / CPB], ci = c % CPB;
         const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 0, h) + (size_t)ci * (CHUNK * HD)) + lane;
         const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 1, h) + (size_t)ci * (CHUNK * HD)) + lane;
-        const int npool = L - 1 - c * CHUNK;                           // tokens of this chunk that live in the pool (the newest one comes from LDS)
+        const int npool = L - 1 - c * CHUNK;
         if (npool >= CHUNK) {
 #pragma unroll
             for (int f = 0; f < 8; ++f) kf[f] = ld_nt(Kp + f * 64);
@@ -1665,29 +1635,84 @@ __global__ __launch_bounds__(1024) void qkv_attention_kernel(QkvAttnArgs p) {
                 }
         }
     };
-    if (w < nc) load_tiles(w);
-    __syncthreads();
-    // ---------------- cross-segment fold + rstd: q / k / v rows of this head as bf16, in LDS
-    if (tid < R * 192) {
-        const int r_ = tid / 192, c_ = tid % 192, j = c_ >> 4, cc = c_ & 15;
-        const int o = (r_ & 3) * 64 + 16 * (r_ >> 2) + cc;             // D[row = 4 (lane >> 4) + reg][col = lane & 15]
-        const float* pj = part + (size_t)j * 4 * 4 * 64;
-        const float v = ((pj[o] + pj[256 + o]) + pj[512 + o]) + pj[768 + o];
-        const float ssum = ((rowsum[r_] + rowsum[16 + r_]) + rowsum[32 + r_]) + rowsum[48 + r_];
-        const float rstd = 1.0f / sqrtf(ssum * (1.0f / 1024.0f) + 1e-5f);
-        qkv_s[r_ * 192 + c_] = (uint16_t)f2bf(v * rstd);
+    // ---- producers, phase 1: the unit's 16 rows x 64 columns, one MFMA chain per (tile, K segment)
+    const int u_mt = unit / 48, u_h = (unit % 48) / 3, u_part = unit % 3;
+    if (producer) {
+        int m = u_mt * 16 + col; m = m < a.rows ? m : a.rows - 1;     // padded rows re-read the last row; their outputs are dropped
+        const uint4* xp = reinterpret_cast<const uint4*>(p.x + (size_t)m * D + sseg * 256 + kg * 8);
+        uint4 af[8];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) af[kb] = xp[kb * 4];
+        f32x4 ss = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nt = u_part * 64 + u_h * 4 + j;                // packed n-tile of the [3072][1024] matrix
+            const uint4* wp = p.wqkv + ((size_t)nt * 32 + sseg * 8) * 64 + lane;
+            uint4 w[8];
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) w[kb] = ld_nt(wp + kb * 64);
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[kb]), as_frag(w[kb]), acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gpart[((j * 4 + sseg) * 4 + r) * 64 + lane] = acc[r];
+        }
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) ss = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[kb]), as_frag(af[kb]), ss, 0, 0, 0);   // diagonal = sum of squares of the segment
+        const int r = col & 3;
+        const float d = r == 0 ? ss[0] : r == 1 ? ss[1] : r == 2 ? ss[2] : ss[3];
+        if ((col >> 2) == kg) growsum[sseg * 16 + col] = d;
     }
-    __syncthreads();                                                   // q / k / v are in place; the partials are dead: their LDS becomes the attention regions
-    // ---------------- phase 2: fused decode attention of row `row`, head h, by the row's WPR waves
-    float* pm = lds + (size_t)row * 66 * a.max_chunks; float* pl = pm + a.max_chunks; float* po = pm + 2 * a.max_chunks;
-    float* sbuf = lds + (size_t)R * 66 * a.max_chunks + wave * 96;
-    uint32_t* stash = reinterpret_cast<uint32_t*>(lds + (size_t)R * 66 * a.max_chunks + 16 * 96) + wave * (12 * 64) + lane;
-    uint16_t* pbuf = reinterpret_cast<uint16_t*>(sbuf + 64);
+    __syncthreads();
+    // ---- producers, phase 2: fold ((s0 + s1) + s2) + s3, rstd, bf16; published write-through, drained
+    if (producer) {
+        const int t = tid & 255, r16 = t >> 4, cq = t & 15, j = cq >> 2, c0 = 4 * (cq & 3);
+        const int m = u_mt * 16 + r16;
+        if (m < a.rows) {
+            const int o = (r16 & 3) * 64 + 16 * (r16 >> 2) + c0;
+            const float* pj = gpart + (size_t)j * 4 * 4 * 64;
+            const float4 s0 = *reinterpret_cast<const float4*>(pj + o), s1 = *reinterpret_cast<const float4*>(pj + 256 + o),
+                         s2 = *reinterpret_cast<const float4*>(pj + 512 + o), s3 = *reinterpret_cast<const float4*>(pj + 768 + o);
+            const float ssum = ((growsum[r16] + growsum[16 + r16]) + growsum[32 + r16]) + growsum[48 + r16];
+            const float rstd = 1.0f / sqrtf(ssum * (1.0f / 1024.0f) + 1e-5f);
+            const uint32_t b0 = f2bf((((s0.x + s1.x) + s2.x) + s3.x) * rstd), b1 = f2bf((((s0.y + s1.y) + s2.y) + s3.y) * rstd),
+                           b2 = f2bf((((s0.z + s1.z) + s2.z) + s3.z) * rstd), b3 = f2bf((((s0.w + s1.w) + s2.w) + s3.w) * rstd);
+            gu64_t* dst = (gu64_t*)(p.qkv + (size_t)m * QKV + u_part * D + u_h * HD + j * 16 + c0);
+            __hip_atomic_store(dst, (unsigned long long)(b0 | (b1 << 16)) | ((unsigned long long)(b2 | (b3 << 16)) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave drains before the flag goes up
+    }
+    __syncthreads();
+    if (producer && sseg == 0 && lane == 0) __hip_atomic_store((gu32_t*)(p.sync + QIA_FLAGS + unit), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the wave's first K/V tile: requested behind the unit so that its 64 registers never coexist with the unit's operands (a workgroup
+    // without a unit gets here two empty barriers after its ticket)
+    if (wave < nc) load_tiles(wave);
+    // ---- every workgroup: wait for the q | k | v units of its (m-tile, head)
+    if (tid == 0) {
+        gu32_t* fl = (gu32_t*)(p.sync + QIA_FLAGS + (row >> 4) * 48 + h * 3);
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned f0 = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), f1 = __hip_atomic_load(fl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                           f2 = __hip_atomic_load(fl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((f0 & f1 & f2) == 1u) break;
+            if (++spins > (1u << 22)) { __hip_atomic_store((gu32_t*)(p.sync + 1), 0xdead0000u | (unsigned)(row & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // give up: wrong ids, not a hang
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    // ---- attention_kernel's fused body; q / k / v pieces by sc1 loads
     uint4 qfrag[2], knf[2];
     uint32_t vnew[4];
     {
         const int pos = L - 1;
-        const uint16_t* src = qkv_s + row * 192;
+        const uint16_t* src = p.qkv + (size_t)row * QKV + h * HD;
+        auto ld16 = [&](const uint16_t* q_) {
+            const unsigned long long lo = __hip_atomic_load((gu64_t*)q_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_load((gu64_t*)(q_ + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        };
+        const uint4 q1 = ld16(src + kg * 8), q2 = ld16(src + 32 + kg * 8), k1 = ld16(src + D + kg * 8), k2 = ld16(src + D + 32 + kg * 8);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vnew[dt] = __hip_atomic_load((gu16_t*)(src + 2 * D + 16 * dt + col), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float c[8], s[8];
         {
             const float4* cp = reinterpret_cast<const float4*>(a.cos_t + (size_t)pos * 32 + kg * 8);
@@ -1696,21 +1721,14 @@ __global__ __launch_bounds__(1024) void qkv_attention_kernel(QkvAttnArgs p) {
             c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
             s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
         }
-        rope8(*reinterpret_cast<const uint4*>(src + kg * 8), *reinterpret_cast<const uint4*>(src + 32 + kg * 8), c, s, qfrag[0], qfrag[1]);
-        rope8(*reinterpret_cast<const uint4*>(src + 64 + kg * 8), *reinterpret_cast<const uint4*>(src + 96 + kg * 8), c, s, knf[0], knf[1]);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) vnew[dt] = src[128 + 16 * dt + col];
-        if (w == 0) {                               // paged write of the newest K / V (for the following steps)
+        rope8(q1, q2, c, s, qfrag[0], qfrag[1]);
+        rope8(k1, k2, c, s, knf[0], knf[1]);
+        if (wave == 0) {                            // paged write of the newest K (8 pieces of 16 bytes); V goes back from the last tile
             const int blk = bt[pos / KV_BLOCK], tok = pos % KV_BLOCK;
             uint16_t* kb = a.kv_layer_w + kv_head_base(blk, 0, h);
-            uint16_t* vb = a.kv_layer_w + kv_head_base(blk, 1, h);
             if (col == 0) {
                 *reinterpret_cast<uint4*>(kb + k_slot(tok, 0, kg)) = knf[0];
                 *reinterpret_cast<uint4*>(kb + k_slot(tok, 1, kg)) = knf[1];
-            }
-            if (kg == 0) {
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) vb[v_elem(tok, 16 * dt + col)] = (uint16_t)vnew[dt];
             }
         }
         stash[0 * 64] = knf[0].x; stash[1 * 64] = knf[0].y; stash[2 * 64] = knf[0].z; stash[3 * 64] = knf[0].w;
@@ -1719,8 +1737,8 @@ __global__ __launch_bounds__(1024) void qkv_attention_kernel(QkvAttnArgs p) {
         for (int dt = 0; dt < 4; ++dt) stash[(8 + dt) * 64] = vnew[dt];
         asm volatile("" ::: "memory");
     }
-    for (int c = w; c < nc; c += WPR) {
-        if (c != w) load_tiles(c);
+    for (int c = wave; c < nc; c += NW) {
+        if (c != wave) load_tiles(c);
         if (c == nc - 1) {                          // the newest token is patched into the last tile
             knf[0] = make_uint4(stash[0 * 64], stash[1 * 64], stash[2 * 64], stash[3 * 64]);
             knf[1] = make_uint4(stash[4 * 64], stash[5 * 64], stash[6 * 64], stash[7 * 64]);
@@ -1740,6 +1758,15 @@ __global__ __launch_bounds__(1024) void qkv_attention_kernel(QkvAttnArgs p) {
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     if (tss == 0) patch16(vf[2 * dt], js, vnew[dt]); else patch16(vf[2 * dt + 1], js, vnew[dt]);
+                }
+                const int blk = bt[c / CPB], ci = c % CPB;
+                uint4* Vw = reinterpret_cast<uint4*>(a.kv_layer_w + kv_head_base(blk, 1, h) + (size_t)ci * (CHUNK * HD)) + lane;
+                if (tss == 0) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) Vw[(2 * dt) * 64] = vf[2 * dt];
+                } else {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) Vw[(2 * dt + 1) * 64] = vf[2 * dt + 1];
                 }
             }
         }
@@ -1782,7 +1809,7 @@ __global__ __launch_bounds__(1024) void qkv_attention_kernel(QkvAttnArgs p) {
         asm volatile("" ::: "memory");
     }
     __syncthreads();
-    if (w == 0) {                                   // fold in ascending chunk order (contract), as attention_kernel does
+    if (wave == 0) {                                // fold in ascending chunk order (contract), as attention_kernel does
         float M = -INFINITY;
         for (int c0 = 0; c0 < nc; c0 += 64) M = fmaxf(M, (c0 + lane < nc) ? pm[c0 + lane] : -INFINITY);
         M = wave_max_f32(M, lane);
@@ -1797,23 +1824,26 @@ __global__ __launch_bounds__(1024) void qkv_attention_kernel(QkvAttnArgs p) {
         a.out[(size_t)row * D + h * HD + lane] = (uint16_t)f2bf(o / l);
     }
 }
-bool qkv_attention_small_fits(int rows, int max_chunks) {
-    return (rows == 2 || rows == 4) && qkv_attn_lds_floats(rows, max_chunks) * sizeof(float) <= 160 * 1024;
+int qkv_in_attention_sync_words(int rows) { return QIA_FLAGS + qia_units(rows); }
+bool qkv_in_attention_fits(int rows, int max_chunks) {
+    const int nw = rows <= 8 ? 8 : 4;
+    // 4-wave form: four workgroups per CU must still fit (the attention's occupancy); 8-wave form: two
+    return rows >= 2 && qia_lds_floats(nw, max_chunks) * sizeof(float) <= (nw == 4 ? 40 * 1024 : 80 * 1024);
 }
-hipError_t launch_qkv_attention_small(const uint16_t* x, const uint4* wqkv, const AttnArgs& a, hipStream_t s) {
-    if (!qkv_attention_small_fits(a.rows, a.max_chunks)) return hipErrorInvalidValue;
-    const size_t lds = qkv_attn_lds_floats(a.rows, a.max_chunks) * sizeof(float);
-    QkvAttnArgs p{x, wqkv, a};
-    static size_t raised[MAX_DEVICES][2] = {};
-    size_t& have = raised[cur_device()][a.rows == 4];
-    if (lds > 64 * 1024 && lds > have) {
-        hipError_t e = a.rows == 2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_attention_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                                   : hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_attention_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+hipError_t launch_qkv_in_attention(const uint16_t* x, const uint4* wqkv, uint16_t* qkv, unsigned* sync, const AttnArgs& a, hipStream_t s) {
+    if (!qkv_in_attention_fits(a.rows, a.max_chunks)) return hipErrorInvalidValue;
+    const int nw = a.rows <= 8 ? 8 : 4;
+    const size_t lds = qia_lds_floats(nw, a.max_chunks) * sizeof(float);
+    QkvInAttnArgs p{x, wqkv, qkv, sync, a};
+    static size_t raised[MAX_DEVICES] = {};
+    size_t& have = raised[cur_device()];
+    if (nw == 8 && lds > 64 * 1024 && lds > have) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_in_attention_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         have = lds;
     }
-    if (a.rows == 2) hipLaunchKernelGGL(qkv_attention_kernel<2>, dim3(H), dim3(1024), lds, s, p);
-    else hipLaunchKernelGGL(qkv_attention_kernel<4>, dim3(H), dim3(1024), lds, s, p);
+    if (nw == 8) hipLaunchKernelGGL(qkv_in_attention_kernel<8>, dim3(H, a.rows), dim3(512), lds, s, p);
+    else hipLaunchKernelGGL(qkv_in_attention_kernel<4>, dim3(H, a.rows), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 

@@ -244,9 +244,10 @@ int t3k_rope_attention(const void* qkv_bf16, const int32_t* row_stream, const in
  * out bf16 [steps][rows][1024]; kv_new (nullable) bf16 [steps][rows][2][1024] = K (rotated) and V of the written positions, read back. */
 int t3k_decode_attention(const void* ctx_qkv_bf16, int32_t n_content, int32_t content_rows, const void* new_qkv_bf16, const int32_t* ctx,
                          int32_t rows, int32_t steps, int32_t max_pos, int32_t waves, void* out_bf16, void* kv_new_bf16);
-/* The one-launch qkv projection + fused decode attention that decode steps of one or two utterances (2 or 4 rows) run per layer: as
- * t3k_decode_attention, but launch s takes the residual rows h_rows[s][r] ([steps][rows][1024] bf16), the RMSNorm weight ln_w [1024] and
- * the layer's qkv matrix wqkv [3072][1024] (q, k, v rows in that order, as the checkpoint holds them) and projects q | k | v itself. */
+/* The qkv projection computed INSIDE the fused decode attention launch (any row count >= 2): as t3k_decode_attention, but launch s takes the
+ * residual rows h_rows[s][r] ([steps][rows][1024] bf16), the RMSNorm weight ln_w [1024] and the layer's qkv matrix wqkv [3072][1024] (q, k, v
+ * rows in that order, as the checkpoint holds them); the launch's first workgroups project q | k | v in units of (16 rows, head, q|k|v) and
+ * hand them to the attention workgroups through flags.  T3_E_DEVICE if a workgroup gave up waiting for a unit. */
 int t3k_qkv_decode_attention(const void* ctx_qkv_bf16, int32_t n_content, int32_t content_rows, const void* h_rows_bf16, const void* ln_w_bf16,
                              const void* wqkv_bf16, const int32_t* ctx, int32_t rows, int32_t steps, int32_t max_pos, void* out_bf16, void* kv_new_bf16);
 /* CFG + sampler: logits bf16 [2][ldl] (cond row, uncond row), counts uint16 [8194] (updated). */
