@@ -216,11 +216,16 @@ __device__ __forceinline__ unsigned a_img_off(int row, int ch) {     // byte off
 #define T3_GEMM2_EW 4
 #endif
 template <int NW> constexpr int gemm2_ew() { return NW == 4 ? T3_GEMM2_EW : 0; }
-template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
+// AV: how many of the KBS A-row instructions per m-tile a wave issues.  An instruction covers RPI consecutive rows, and the texture
+// path charges a padded row like a real one: a decode step of 1-4 utterances has 2-8 rows in its 16-row tile, and at 2 rows the
+// padding was as many bytes through the CU's load path as the workgroup's weights.  The launcher picks the smallest AV whose rows
+// cover M (one m-tile, one m-group); the image rows beyond are zero (row m of the accumulator depends on image row m alone, and
+// rows >= M are never stored).  A template parameter, not a branch: conditional asm loads make hipcc build the register tuples by copies.
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM, int AV = KBS>
 __global__ __launch_bounds__((NW + gemm2_ew<NW>()) * 64) void gemm2_kernel(GemmArgs a) {
     T3_G2STAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];      // [NW waves][MT][16 rows][KBS * 64 B] | NORM: float [NW][MT*16]
-    static_assert(NT <= KBS && (KBS == 8 || KBS == 2) && (NW == 4 || NW == 16), "gemm2 shapes");
+    static_assert(NT <= KBS && (KBS == 8 || KBS == 2) && (NW == 4 || NW == 16) && AV >= 1 && AV <= KBS && (AV == KBS || MT == 1), "gemm2 shapes");
     constexpr int LPR = KBS * 4, RPI = 64 / LPR;                // lanes (= 16-byte chunks) per row slice, rows per wave instruction
     constexpr int ABYTES = MT * KBS * 1024, TILES = MT * NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -258,8 +263,10 @@ __global__ __launch_bounds__((NW + gemm2_ew<NW>()) * 64) void gemm2_kernel(GemmA
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int t = 0; t < KBS; ++t)
+        for (int t = 0; t < KBS; ++t) {
+            if constexpr (AV < KBS) { if (t >= AV) { ar[i][t] = (uint4_v){0u, 0u, 0u, 0u}; continue; } }
             gload16(ar[i][t], a.X + (size_t)mrow[i][t] * a.K + kb0 * 32 + ch * 8);
+        }
     // ---- W: every tile of this wave's K slice, behind the A loads and before the first wait (left to itself, hipcc sinks these
     // loads below the staging block to save registers, i.e. behind a full L2 round trip)
     uint4_v wr[KBS][NT];
@@ -272,7 +279,7 @@ __global__ __launch_bounds__((NW + gemm2_ew<NW>()) * 64) void gemm2_kernel(GemmA
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int t = 0; t < KBS; ++t) landed(ar[i][t]);
+        for (int t = 0; t < AV; ++t) landed(ar[i][t]);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -850,10 +857,10 @@ constexpr int MAX_DEVICES = 64;
 static inline int cur_device() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < MAX_DEVICES ? d : 0; }
 
 // gemm2_kernel launcher; a == nullptr: only raise the kernel's dynamic-LDS limit (prepare_kernels, before any stream capture)
-template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
-static hipError_t launch_gemm2_t(const GemmArgs* a, hipStream_t s) {
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM, int AV>
+static hipError_t launch_gemm2_av(const GemmArgs* a, hipStream_t s) {
     constexpr size_t lds = (size_t)NW * MT * KBS * 1024 + (NORM ? (size_t)NW * MT * 16 * sizeof(float) : 0);
-    auto kern = gemm2_kernel<MT, NT, EPI, NW, KBS, NORM>;
+    auto kern = gemm2_kernel<MT, NT, EPI, NW, KBS, NORM, AV>;
     static bool raised[MAX_DEVICES] = {};
     if (lds > 64 * 1024 && !raised[cur_device()]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -866,6 +873,30 @@ static hipError_t launch_gemm2_t(const GemmArgs* a, hipStream_t s) {
     const int gy = ((a->M + 15) / 16 + MT - 1) / MT;
     hipLaunchKernelGGL(kern, dim3(gx, gy), dim3((NW + gemm2_ew<NW>()) * 64), lds, s, *a);
     return hipGetLastError();
+}
+// picks AV (see gemm2_kernel): the fewest A-row instructions that cover the rows of a one-tile call
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
+static hipError_t launch_gemm2_t(const GemmArgs* a, hipStream_t s) {
+    if constexpr (MT == 1) {
+        constexpr int RPI = 64 / (KBS * 4);            // rows per A instruction: 2 (KBS 8) or 8 (KBS 2)
+        static int small = -1;
+        if (small < 0) { const char* e = getenv("T3_GEMM_SMALL_M"); small = e ? atoi(e) : 1; }
+        if (!a) {
+            hipError_t e;
+            if ((e = launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, 1>(a, s)) != hipSuccess) return e;
+            if constexpr (KBS == 8) {
+                if ((e = launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, 2>(a, s)) != hipSuccess) return e;
+                if ((e = launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, 4>(a, s)) != hipSuccess) return e;
+            }
+        } else if (small && a->M <= 16) {
+            if (a->M <= RPI) return launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, 1>(a, s);
+            if constexpr (KBS == 8) {
+                if (a->M <= 2 * RPI) return launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, 2>(a, s);
+                if (a->M <= 4 * RPI) return launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, 4>(a, s);
+            }
+        }
+    }
+    return launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, KBS>(a, s);
 }
 // looped NORM form (>= 4 m-groups of 32 rows, no row gather): one workgroup per n-group, weights stationary in registers
 template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>

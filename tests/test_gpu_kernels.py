@@ -118,6 +118,29 @@ def test_gate_up_silu_bit_exact(E, oracle, M):
     assert_bit_equal(got, oracle.silu_mul(g, u), "silu(gate)*up with folded norm")
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8, 9, 14, 16])
+def test_decode_gemms_at_few_rows(E, oracle, M):
+    """Decode steps of 1-8 utterances: the one-tile GEMMs issue only the activation-row loads that hold rows (gemm2_kernel's AV forms:
+    1, 2, 4 of 8 instructions at <= 2, 4, 8 rows for the 512-byte slices, 1 of 2 at <= 8 rows for the 128-byte ones).  Every form the
+    step runs -- qkv, o + residual, gate/up, down + residual, the speech head over gathered rows -- against the same oracle functions."""
+    h = rand_bf16(M, 1024, seed=M, scale=2.0); ln = (rand_bf16(1024, seed=9) + 1.0).to(torch.bfloat16)
+    W = rand_bf16(3072, 1024, seed=21, scale=0.05)
+    assert_bit_equal(E.k_norm_gemm(h, ln, W), oracle.norm_gemm(h, ln, W), f"qkv form M={M}")
+    for n in (16, 48, 64):                                  # tile groups of 1, 3, 4
+        assert_bit_equal(E.k_norm_gemm(h, ln, W[:n]), oracle.norm_gemm(h, ln, W[:n]), f"norm+gemm N={n} M={M}")
+    Wg = rand_bf16(512, 1024, seed=2, scale=0.1); Wu = rand_bf16(512, 1024, seed=3, scale=0.1)
+    g = oracle.norm_gemm(h, ln, Wg).to(torch.bfloat16); u = oracle.norm_gemm(h, ln, Wu).to(torch.bfloat16)
+    assert_bit_equal(E.k_silu_mul_gemm(h, ln, Wg, Wu), oracle.silu_mul(g, u), f"gate/up M={M}")
+    for K in (1024, 4096):
+        x = rand_bf16(M, K, seed=M + K); Wo = rand_bf16(1024, K, seed=4, scale=0.05); res = rand_bf16(M, 1024, seed=5, scale=2.0)
+        y = oracle.gemm(x, Wo, K // 16).to(torch.bfloat16)
+        assert_bit_equal(E.k_gemm_resid(x, Wo, res), (res.float() + y.float()).to(torch.bfloat16), f"residual epilogue K={K} M={M}")
+        assert_bit_equal(E.k_gemm(x, Wo[:64], nw=16), oracle.gemm(x, Wo[:64], K // 16), f"16-segment gemm K={K} M={M}")
+    big = rand_bf16(40, 1024, seed=1, scale=2.0); idx = [(7 * i + 3) % 40 for i in range(M)]
+    Wh = rand_bf16(160, 1024, seed=3, scale=0.05)
+    assert_bit_equal(E.k_norm_gemm(big, ln, Wh, row_index=idx), oracle.norm_gemm(big[idx], ln, Wh), f"gathered rows M={M}")
+
+
 def _oracle_rope_attention(oracle, qkv, row_stream, row_pos, n_streams, max_pos):
     cos_t, sin_t = oracle.rope_table(max_pos)
     pos = torch.tensor(row_pos, dtype=torch.int32)
