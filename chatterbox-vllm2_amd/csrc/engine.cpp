@@ -77,6 +77,8 @@ struct T3Engine {
     int n_groups = 1;
     int row_stride = 0;        // int32 words per row record
     bool fuse_rope = true;
+    int prefetch_down_lines = 768;    // T3_PREFETCH_DOWN_LINES: 128-byte lines of every down_proj tile (1024) the gate/up launch fetches
+    int prefetch = 1;                 // T3_PREFETCH=0: gate/up's epilogue waves do not fetch down_proj's weights into L2
     bool qkv_in_attn = false;         // T3_QKV_IN_ATTN=1: decode-only steps run the qkv projection inside the attention launch (units + flags, t3_kernels.hip)
 
     // weights (device)
@@ -210,6 +212,8 @@ extern "C" int t3_create(const T3EngineConfig* cfg, T3Handle* out) {
         e->groups.resize(e->n_groups);
         if (const char* ev = getenv("T3_FUSE_ROPE")) e->fuse_rope = atoi(ev) != 0;
         if (const char* ev = getenv("T3_QKV_IN_ATTN")) e->qkv_in_attn = atoi(ev) != 0;
+        if (const char* ev = getenv("T3_PREFETCH")) e->prefetch = atoi(ev);
+        if (const char* ev = getenv("T3_PREFETCH_DOWN_LINES")) e->prefetch_down_lines = atoi(ev);
         if (const char* ev = getenv("T3_RUN_AHEAD")) e->run_ahead = atoi(ev) != 0;
         e->antiphase = e->n_groups == 2;
         if (const char* ev = getenv("T3_ANTIPHASE")) e->antiphase = atoi(ev) != 0 && e->n_groups == 2;
@@ -614,7 +618,14 @@ static int launch_mlp_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::Ste
     LayerW& y = e->layers[L];
     const int M = sr.M;
     { Prof p(e, K_O, s); GemmArgs a{g.att, (const uint4*)y.o, M, D, D, g.h, D, 16, 0, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
-    { Prof p(e, K_GU, s); GemmArgs a{g.h, (const uint4*)y.gu, M, D, F, g.act, F, 4, 1, nullptr, 0, g.rstd}; HIP_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s)); }
+    {
+        Prof p(e, K_GU, s); GemmArgs a{g.h, (const uint4*)y.gu, M, D, F, g.act, F, 4, 1, nullptr, 0, g.rstd};
+        // down_proj at <= 80 rows is one workgroup per n-tile (64 tiles of 128 KiB, XCD = tile mod 8): gate/up's epilogue waves fetch the head
+        // of every tile into L2 while they fold (nothing else is in flight then).  C3: 20.73 -> 20.91 / 20.98 / 20.96 k tok/s at 512 / 768 / 1024
+        // of a tile's 1024 lines (profiles/r03_prefetch_*.json); B = 1: no difference
+        if (e->prefetch && M <= 80) a.pf = PrefetchArgs{reinterpret_cast<const unsigned char*>(y.down), D / 16, (F / 32) * 8, 1, e->prefetch_down_lines};
+        HIP_TRY(launch_gemm(a, EPI_SILU, choose_mt(M, F / 16, 4, true), s));
+    }
     { Prof p(e, K_DOWN, s); GemmArgs a{g.act, (const uint4*)y.down, M, F, D, g.h, D, 16, 0, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
     return T3_OK;
 }

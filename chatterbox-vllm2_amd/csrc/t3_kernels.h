@@ -24,6 +24,19 @@ constexpr int KV_BLOCK_ELEMS = 2 * H * KV_HEAD_ELEMS;  // per layer per block: [
 
 enum GemmEpi { EPI_F32 = 0, EPI_BF16 = 1, EPI_RESID = 2, EPI_SILU = 3 };
 
+// Weights of a LATER launch on the stream, pulled into the L2 of the XCD that will read them while this launch leaves the memory system
+// idle: the fold + epilogue of a 4-wave GEMM form (0.4-1.3 us with nothing in flight).  The consumer is a gemm2_kernel whose workgroup bx
+// reads the `group` packed n-tiles bx * group ... (tile_lines 128-byte lines each, contiguous); block b of EVERY launch lands on XCD
+// (x0 + b) % 8 with the same x0 (tools/xcd_probe.hip: eager and graph launches, 1-D and 2-D grids of any size), so the lines of tile group g
+// are requested by workgroups of this launch whose linear id is g mod 8, one line per lane and instruction, by LDS-DMA into a 256-byte
+// corner of LDS nobody reads (a load into a register would be written whenever it lands, long after the compiler has given the register
+// to something else: that build faulted).  Speed only: nothing depends on where the lines end up.
+struct PrefetchArgs {
+    const unsigned char* base = nullptr;   // null: nothing to prefetch
+    int n_tiles = 0, tile_lines = 0, group = 1;
+    int max_lines = 0;                     // > 0: only the first max_lines lines of every tile group
+};
+
 struct GemmArgs {
     const uint16_t* X;   // [M][K] bf16 row-major (NORM form: the un-normalised residual stream)
     const uint4* Wp;     // packed weight, see pack_weight() (NORM form: with the norm weight folded in, fold_norm_weight())
@@ -35,6 +48,7 @@ struct GemmArgs {
     const int* row_index;    // optional gather: source row of X per GEMM row (speech head over the sampled rows)
     int packed_tiles = 0;    // > 0: the packed weight holds this many n-tiles (zero rows beyond N), so tile groups may overhang N
     float* rstd_scratch = nullptr;   // [M] floats: lets the NORM forms take the prefill-sized schedule (row statistic in its own pass)
+    PrefetchArgs pf;                 // gemm2_kernel, 4-wave forms: requested by the epilogue waves once the workgroup's own operands have landed
 };
 
 // Host-side packing of a [N][K] bf16 matrix into MFMA-B-operand order:

@@ -208,6 +208,27 @@ __device__ __forceinline__ unsigned a_img_off(int row, int ch) {     // byte off
     else return (unsigned)(row * (KBS * 64) + ((ch ^ ((row >> 1) & (KBS * 4 - 1))) << 4));          // 128-byte rows: two rows per bank row
 }
 
+// PrefetchArgs (t3_kernels.h): this workgroup's share of a later launch's weight lines.  cls = this workgroup's XCD (its linear id % 8),
+// idx / n = its index among / the number of (workgroup, wave) slots of that XCD that take part; dump = LDS byte address (wave-uniform) of
+// 256 bytes nobody reads.  The loads count in vmcnt like any other and retire in issue order: issue them BEHIND every load the wave
+// still waits for; nothing waits for them (s_endpgm does).
+__device__ __forceinline__ void prefetch_next_weights(const PrefetchArgs& pf, int cls, int idx, int n, int lane, unsigned dump) {
+    if (!pf.base) return;
+    const int groups = pf.n_tiles / pf.group, groups_cls = (groups - cls + 7) >> 3;
+    const int glines = pf.max_lines > 0 && pf.max_lines < pf.group * pf.tile_lines ? pf.max_lines : pf.group * pf.tile_lines;
+    const int total = groups_cls * glines, cnt = (total + n - 1) / n;
+    for (int j = 0; j * 64 < cnt && j < 32; ++j) {
+        const int k = lane + 64 * j, l = idx * cnt + k;
+        if (k < cnt && l < total) {
+            const int g = cls + 8 * (l / glines), rem = l % glines;
+            const unsigned char* p = pf.base + ((size_t)g * pf.group * pf.tile_lines + rem) * 128;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(p), "s"(dump) : "memory");
+        }
+    }
+}
+
 // EW: extra waves that sleep at the barrier and then share the epilogue.  The fold + epilogue of the 4-wave forms is a dependent chain of
 // ~300 vector instructions per thread (eight LDS reads, rstd, four SiLU-mul outputs with correctly rounded divisions) issued by ONE wave per
 // SIMD: 1.32 us of gate/up's 6.1 us, 0.52 of qkv's 3.6 (stamps, profiles/r03_gemm_clk_m64.txt).  With four more waves every thread
@@ -333,6 +354,15 @@ __global__ __launch_bounds__((NW + gemm2_ew<NW>()) * 64) void gemm2_kernel(GemmA
     }                                     // compute waves
     __syncthreads();
     T3_G2STAMP(4);
+    if constexpr (EW > 0) {
+        // PrefetchArgs: every operand of the workgroup has landed and the memory system idles until the stores: the epilogue waves ask for
+        // their share of the next launch's weights before they start folding (dump corner: the 256 bytes behind everything else in LDS)
+        if (wave >= NW && ((gridDim.x * gridDim.y) & 7) == 0) {
+            const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+            const unsigned dump = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(lds2 + (size_t)NW * ABYTES + (NORM ? NW * MT * 16 * sizeof(float) : 0));
+            prefetch_next_weights(a.pf, lin & 7, (lin >> 3) * EW + (wave - NW), ((gridDim.x * gridDim.y) >> 3) * EW, lane, dump);
+        }
+    }
     auto part = [&](int w) { return reinterpret_cast<const float*>(lds2 + (size_t)w * ABYTES); };
 
     if constexpr (NW == 4) {
@@ -859,7 +889,7 @@ static inline int cur_device() { int d = 0; (void)hipGetDevice(&d); return d >= 
 // gemm2_kernel launcher; a == nullptr: only raise the kernel's dynamic-LDS limit (prepare_kernels, before any stream capture)
 template <int MT, int NT, int EPI, int NW, int KBS, bool NORM, int AV>
 static hipError_t launch_gemm2_av(const GemmArgs* a, hipStream_t s) {
-    constexpr size_t lds = (size_t)NW * MT * KBS * 1024 + (NORM ? (size_t)NW * MT * 16 * sizeof(float) : 0);
+    constexpr size_t lds = (size_t)NW * MT * KBS * 1024 + (NORM ? (size_t)NW * MT * 16 * sizeof(float) : 0) + (gemm2_ew<NW>() ? 256 : 0);    // + the prefetch dump corner
     auto kern = gemm2_kernel<MT, NT, EPI, NW, KBS, NORM, AV>;
     static bool raised[MAX_DEVICES] = {};
     if (lds > 64 * 1024 && !raised[cur_device()]) {
