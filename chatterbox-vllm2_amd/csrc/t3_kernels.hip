@@ -214,7 +214,7 @@ __device__ __forceinline__ unsigned a_img_off(int row, int ch) {     // byte off
 // still waits for; nothing waits for them (s_endpgm does).
 __device__ __forceinline__ void prefetch_next_weights(const PrefetchArgs& pf, int cls, int idx, int n, int lane, unsigned dump) {
     if (!pf.base) return;
-    const int groups = pf.n_tiles / pf.group, groups_cls = (groups - cls + 7) >> 3;
+    const int groups = pf.n_tiles / pf.group, groups_cls = groups >> 3;      // callers: groups is a multiple of 8
     const int glines = pf.max_lines > 0 && pf.max_lines < pf.group * pf.tile_lines ? pf.max_lines : pf.group * pf.tile_lines;
     const int total = groups_cls * glines, cnt = (total + n - 1) / n;
     for (int j = 0; j * 64 < cnt && j < 32; ++j) {
