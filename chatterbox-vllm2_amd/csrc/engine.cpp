@@ -18,6 +18,7 @@
 #include <map>
 #include <string>
 #include <unordered_map>
+#include <tuple>
 #include <vector>
 
 #include "t3_kernels.h"
@@ -78,6 +79,7 @@ struct T3Engine {
     int row_stride = 0;        // int32 words per row record
     bool fuse_rope = true;
     int prefetch_down_lines = 768;    // T3_PREFETCH_DOWN_LINES: 128-byte lines of every down_proj tile (1024) the gate/up launch fetches
+    bool zero_copy = true;            // T3_ZERO_COPY=0: the step's metadata / sampled ids travel by hipMemcpyAsync (two copy kernels per step) instead of being read / written in pinned host memory by the step's own kernels
     int prefetch = 1;                 // T3_PREFETCH=0: gate/up's epilogue waves do not fetch down_proj's weights into L2
     bool qkv_in_attn = false;         // T3_QKV_IN_ATTN=1: decode-only steps run the qkv projection inside the attention launch (units + flags, t3_kernels.hip)
 
@@ -109,7 +111,7 @@ struct T3Engine {
         int* h_out_tok[2] = {nullptr, nullptr};
         hipEvent_t ev_done[2] = {nullptr, nullptr};
         int rcap = 0;              // row budget per step
-        std::map<std::pair<int, int>, hipGraphExec_t> graphs;   // (M, n_sel) -> captured decode step
+        std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;   // (M, n_sel, staging buffer) -> captured decode step
     };
     // One enqueued step: what the scheduler put on each group's stream, kept until its tokens are back.
     struct StepRec {
@@ -133,7 +135,7 @@ struct T3Engine {
     hipStream_t side_stream = nullptr;                   // the second track's branch
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_att;                      // [layer][track]: that track's attention of that layer has finished
-    std::map<std::array<int, 4>, hipGraphExec_t> graphs2;   // (M0, n_sel0, M1, n_sel1) -> captured two-track decode step
+    std::map<std::array<int, 5>, hipGraphExec_t> graphs2;   // (M0, n_sel0, M1, n_sel1, staging buffer) -> captured two-track decode step
     unsigned step_seq = 0;
     bool run_ahead = true;     // t3_run_steps / t3_run_until_done enqueue step N+1 before reading step N's tokens
     int64_t graph_captures = 0; double graph_capture_ms = 0;      // T3_GRAPH_STATS=1 prints them at destroy
@@ -213,6 +215,7 @@ extern "C" int t3_create(const T3EngineConfig* cfg, T3Handle* out) {
         if (const char* ev = getenv("T3_FUSE_ROPE")) e->fuse_rope = atoi(ev) != 0;
         if (const char* ev = getenv("T3_QKV_IN_ATTN")) e->qkv_in_attn = atoi(ev) != 0;
         if (const char* ev = getenv("T3_PREFETCH")) e->prefetch = atoi(ev);
+        if (const char* ev = getenv("T3_ZERO_COPY")) e->zero_copy = atoi(ev) != 0;
         if (const char* ev = getenv("T3_PREFETCH_DOWN_LINES")) e->prefetch_down_lines = atoi(ev);
         if (const char* ev = getenv("T3_RUN_AHEAD")) e->run_ahead = atoi(ev) != 0;
         e->antiphase = e->n_groups == 2;
@@ -564,9 +567,14 @@ static bool step_fuses_qkv(const T3Engine* e, const T3Engine::StepRec& sr) {
     return e->qkv_in_attn && e->fuse_rope && sr.n_prefill_rows == 0 && sr.M >= 2 && sr.M <= 2 * ((e->cfg.max_seqs + e->n_groups - 1) / e->n_groups) &&
            qkv_in_attention_fits(sr.M, (e->cfg.max_model_len + CHUNK - 1) / CHUNK);
 }
-static int launch_embed_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, hipStream_t s) {
+static int launch_embed_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int buf, hipStream_t s) {
     Prof p(e, K_EMBED, s);
     EmbedArgs ea{g.dm.rows, e->row_stride, e->d_cond, e->text_emb, e->text_pos, e->speech_emb, e->speech_pos, g.h, sr.M, g.dm.out_tok};
+    if (e->zero_copy) {       // the step's metadata comes straight out of the pinned buffer the scheduler filled (enqueue_step)
+        ea.host_meta = reinterpret_cast<const int4*>(g.h_meta[buf]); ea.dev_meta = reinterpret_cast<int4*>(g.d_meta);
+        ea.meta_vec = (int)((g.meta_rows_off + (size_t)sr.M * e->row_stride * 4) / 16);
+        ea.host_rowrec = g.hm[buf].rows;
+    }
     if (step_fuses_qkv(e, sr)) { ea.zero_words = g.sync; ea.n_zero = e->cfg.n_layers * g.sync_stride; }
     HIP_TRY(launch_embed(ea, s));
     if (e->d_dbg_emb) HIP_TRY(hipMemcpyAsync(e->d_dbg_emb, g.h, (size_t)sr.M * D * 2, hipMemcpyDeviceToDevice, s));
@@ -629,17 +637,17 @@ static int launch_mlp_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::Ste
     { Prof p(e, K_DOWN, s); GemmArgs a{g.act, (const uint4*)y.down, M, F, D, g.h, D, 16, 0, nullptr}; HIP_TRY(launch_gemm(a, EPI_RESID, choose_mt(M, D / 16, 16, false), s)); }
     return T3_OK;
 }
-static int launch_sample_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, hipStream_t s) {
+static int launch_sample_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int buf, hipStream_t s) {
     const int n_sel = sr.n_sel;
     if (n_sel <= 0) return T3_OK;
     // final RMSNorm folded into the speech-head GEMM, which gathers the sampled rows itself
     { Prof p(e, K_HEAD, s); GemmArgs a{g.h, (const uint4*)e->head, 2 * n_sel, D, V, g.logits, VPAD, 4, 1, g.dm.sel_rows, HEAD_TILES}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16, 4, true), s)); }
-    { Prof p(e, K_SAMPLE, s); SampleArgs sa{g.logits, VPAD, g.dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, g.dm.out_tok, e->d_dbg, n_sel, e->d_hist, e->cfg.max_model_len}; HIP_TRY(launch_sampler(sa, s)); }
+    { Prof p(e, K_SAMPLE, s); SampleArgs sa{g.logits, VPAD, g.dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, g.dm.out_tok, e->d_dbg, n_sel, e->d_hist, e->cfg.max_model_len, e->zero_copy ? g.h_out_tok[buf] : nullptr}; HIP_TRY(launch_sampler(sa, s)); }
     return T3_OK;
 }
-static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, hipStream_t s) {
+static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int buf, hipStream_t s) {
     int rc;
-    if ((rc = launch_embed_phase(e, g, sr, s))) return rc;
+    if ((rc = launch_embed_phase(e, g, sr, buf, s))) return rc;
     const bool fused_qkv = step_fuses_qkv(e, sr);
     for (int L = 0; L < e->cfg.n_layers; ++L) {
         if (fused_qkv) {
@@ -650,7 +658,7 @@ static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec&
         }
         if ((rc = launch_mlp_phase(e, g, sr, L, s))) return rc;
     }
-    return launch_sample_phase(e, g, sr, s);
+    return launch_sample_phase(e, g, sr, buf, s);
 }
 // The two-track schedule of a decode-only step (T3Engine::antiphase): track 0 on `s0`, track 1 on the side stream, forked from and
 // joined back into s0; the attention launches pass a token A(0) -> B(0) -> A(1) -> B(1) ... so that at any time at most one track
@@ -660,7 +668,7 @@ static int launch_step_two_tracks(T3Engine* e, const T3Engine::Step& st, hipStre
     int rc;
     HIP_TRY(hipEventRecord(e->ev_fork, s0));
     HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
-    for (int t = 0; t < 2; ++t) if ((rc = launch_embed_phase(e, e->groups[t], st.g[t], ss[t]))) return rc;
+    for (int t = 0; t < 2; ++t) if ((rc = launch_embed_phase(e, e->groups[t], st.g[t], st.buf, ss[t]))) return rc;
     for (int L = 0; L < e->cfg.n_layers; ++L)
         for (int t = 0; t < 2; ++t) {
             if ((rc = launch_qkv_phase(e, e->groups[t], st.g[t], L, ss[t]))) return rc;
@@ -669,7 +677,7 @@ static int launch_step_two_tracks(T3Engine* e, const T3Engine::Step& st, hipStre
             HIP_TRY(hipEventRecord(e->ev_att[2 * L + t], ss[t]));
             if ((rc = launch_mlp_phase(e, e->groups[t], st.g[t], L, ss[t]))) return rc;
         }
-    for (int t = 0; t < 2; ++t) if ((rc = launch_sample_phase(e, e->groups[t], st.g[t], ss[t]))) return rc;
+    for (int t = 0; t < 2; ++t) if ((rc = launch_sample_phase(e, e->groups[t], st.g[t], st.buf, ss[t]))) return rc;
     HIP_TRY(hipEventRecord(e->ev_join, e->side_stream));
     HIP_TRY(hipStreamWaitEvent(s0, e->ev_join, 0));
     return T3_OK;
@@ -748,20 +756,20 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
         if (sr.M == 0) continue;
         hipStream_t s = stream_of(gi);
         HIP_TRY(hipStreamWaitEvent(s, e->ev_admit, 0));
-        HIP_TRY(hipMemcpyAsync(g.d_meta, g.h_meta[buf], g.meta_rows_off + (size_t)sr.M * e->row_stride * 4, hipMemcpyHostToDevice, s));   // sel arrays + the used row records
+        if (!e->zero_copy) HIP_TRY(hipMemcpyAsync(g.d_meta, g.h_meta[buf], g.meta_rows_off + (size_t)sr.M * e->row_stride * 4, hipMemcpyHostToDevice, s));   // sel arrays + the used row records
         if (e->d_dbg_emb) {
             e->dbg_emb_rec.resize((size_t)2 * sr.M);
             for (int r = 0; r < sr.M; ++r) { const int* rec = g.hm[buf].rows + (size_t)r * e->row_stride; e->dbg_emb_rec[2 * r] = rec[0]; e->dbg_emb_rec[2 * r + 1] = rec[1]; }
         }
         if (two_tracks) continue;                        // launched below, both tracks in one go
         if (graphs_ok) {
-            const auto key = std::make_pair(sr.M, sr.n_sel);
+            const auto key = std::make_tuple(sr.M, sr.n_sel, e->zero_copy ? buf : 0);      // zero-copy: the pinned buffers of `buf` are kernel arguments
             auto it = g.graphs.find(key);
             if (it == g.graphs.end()) {
                 hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
                 const auto tc0 = std::chrono::steady_clock::now();
                 HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                const int lrc = launch_step(e, g, sr, s);
+                const int lrc = launch_step(e, g, sr, buf, s);
                 const hipError_t ce = hipStreamEndCapture(s, &graph);
                 if (lrc) return lrc;
                 HIP_TRY(ce);
@@ -778,15 +786,15 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
             HIP_TRY(hipGraphLaunch(it->second, s));
         } else {
             int lrc;
-            if ((lrc = launch_step(e, g, sr, s))) return lrc;
+            if ((lrc = launch_step(e, g, sr, buf, s))) return lrc;
         }
-        if (sr.n_sel > 0) HIP_TRY(hipMemcpyAsync(g.h_out_tok[buf], g.dm.out_tok, (size_t)sr.n_sel * 4, hipMemcpyDeviceToHost, s));
+        if (sr.n_sel > 0 && !e->zero_copy) HIP_TRY(hipMemcpyAsync(g.h_out_tok[buf], g.dm.out_tok, (size_t)sr.n_sel * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(g.ev_done[buf], s));
     }
     if (two_tracks) {
         hipStream_t s = e->groups[0].stream;
         if (graphs_ok) {
-            const std::array<int, 4> key{st.g[0].M, st.g[0].n_sel, st.g[1].M, st.g[1].n_sel};
+            const std::array<int, 5> key{st.g[0].M, st.g[0].n_sel, st.g[1].M, st.g[1].n_sel, e->zero_copy ? buf : 0};
             auto it = e->graphs2.find(key);
             if (it == e->graphs2.end()) {
                 hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
@@ -813,7 +821,7 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
         }
         for (int gi = 0; gi < 2; ++gi) {
             T3Engine::Group& g = e->groups[gi];
-            if (st.g[gi].n_sel > 0) HIP_TRY(hipMemcpyAsync(g.h_out_tok[buf], g.dm.out_tok, (size_t)st.g[gi].n_sel * 4, hipMemcpyDeviceToHost, s));
+            if (st.g[gi].n_sel > 0 && !e->zero_copy) HIP_TRY(hipMemcpyAsync(g.h_out_tok[buf], g.dm.out_tok, (size_t)st.g[gi].n_sel * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipEventRecord(g.ev_done[buf], s));
         }
     }

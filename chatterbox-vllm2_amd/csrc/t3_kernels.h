@@ -78,6 +78,10 @@ struct EmbedArgs {
     int rows;
     const int* prev_tok;       // the sampler's output array of the previous step (EMB_SPEECH_PREV)
     unsigned* zero_words = nullptr; int n_zero = 0;     // words this launch sets to 0 (the step's hand-off state), nullable
+    // The step's metadata (selection arrays + row records) as the host wrote it, in pinned host memory: this launch reads its own row
+    // records from there and leaves the device copy every later launch of the step reads (no copy kernel in front of the step).
+    const int4* host_meta = nullptr; int4* dev_meta = nullptr; int meta_vec = 0;      // meta_vec 16-byte pieces
+    const int* host_rowrec = nullptr;                                               // rowrec's twin inside host_meta
 };
 enum EmbedKind { EMB_COND = 0 /*a=slot,b=idx*/, EMB_TEXT = 1 /*a=id,b=pos*/, EMB_ZERO = 2, EMB_SPEECH = 3 /*a=id,b=pos*/,
                  EMB_SPEECH_PREV = 4 /*a=index into prev_tok,b=pos*/ };
@@ -131,6 +135,7 @@ struct SampleArgs {
     int n;
     int* hist = nullptr;       // nullable: [max_seqs][hist_cap] speech-space ids of every utterance, kept on the device (f4 hand-off)
     int hist_cap = 0;
+    int* out_tok_host = nullptr;   // nullable: [n] in pinned host memory, written beside out_tok (no copy kernel behind the step)
 };
 hipError_t launch_sampler(const SampleArgs& a, hipStream_t s);
 hipError_t prepare_kernels();   // one-time function attributes (must run before any stream capture)

@@ -1140,9 +1140,10 @@ __device__ __forceinline__ uint4 add_bf8(const uint4& a, const uint4& b) {
 __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
     // the first kernel of a step also zeroes the step's hand-off words (tickets and flags of the qkv-in-attention launches)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n_zero; i += gridDim.x * 256) a.zero_words[i] = 0u;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.meta_vec; i += gridDim.x * 256) a.dev_meta[i] = a.host_meta[i];
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
-    const int* rec = a.rowrec + (size_t)row * a.row_stride;
+    const int* rec = (a.host_rowrec ? a.host_rowrec : a.rowrec) + (size_t)row * a.row_stride;
     int4 d = make_int4(rec[2], rec[3], rec[4], 0);
     if (d.x == EMB_SPEECH_PREV) { d.x = EMB_SPEECH; d.y = a.prev_tok[d.y]; }   // token sampled by the step still in flight when this one was scheduled
     uint4* out = reinterpret_cast<uint4*>(a.h + (size_t)row * D);
@@ -2392,6 +2393,7 @@ __global__ __launch_bounds__(STH) void sampler_kernel(SampleArgs a) {
     if (tid == 0) {
         token = token < 0 ? 0 : (token >= V ? V - 1 : token);       // counts[] / speech_emb[] are indexed with it
         a.out_tok[u] = token;
+        if (a.out_tok_host) a.out_tok_host[u] = token;
         if (a.hist && (int)step < a.hist_cap) a.hist[(size_t)slot * a.hist_cap + step] = token;      // the utterance's ids stay on the device
         const uint16_t cnt = counts[token];
         if (cnt < 65535) counts[token] = cnt + 1;
