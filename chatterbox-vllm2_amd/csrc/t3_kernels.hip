@@ -815,6 +815,7 @@ __global__ __launch_bounds__(256, WC == 4 ? 2 : (NSEG == 4 ? 4 : 3)) void pgemm_
 }
 
 static int g_pgemm_min_rows = -1, g_pgemm_wide_rows = -1;
+static int g_gemm_small_m = 1;          // T3_GEMM_SMALL_M=0: the one-tile GEMMs issue every activation-row load (read again by every prepare_kernels call, i.e. per engine)
 void set_pgemm_min_rows(int rows) { g_pgemm_min_rows = rows; }
 void set_pgemm_wide_rows(int rows) { g_pgemm_wide_rows = rows; }
 
@@ -909,8 +910,7 @@ template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
 static hipError_t launch_gemm2_t(const GemmArgs* a, hipStream_t s) {
     if constexpr (MT == 1) {
         constexpr int RPI = 64 / (KBS * 4);            // rows per A instruction: 2 (KBS 8) or 8 (KBS 2)
-        static int small = -1;
-        if (small < 0) { const char* e = getenv("T3_GEMM_SMALL_M"); small = e ? atoi(e) : 1; }
+        const int small = g_gemm_small_m;
         if (!a) {
             hipError_t e;
             if ((e = launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, 1>(a, s)) != hipSuccess) return e;
@@ -2403,6 +2403,7 @@ __global__ __launch_bounds__(STH) void sampler_kernel(SampleArgs a) {
     }
 }
 hipError_t prepare_kernels() {
+    { const char* ev = getenv("T3_GEMM_SMALL_M"); g_gemm_small_m = ev ? atoi(ev) : 1; }
     static bool done[MAX_DEVICES] = {};
     if (done[cur_device()]) return hipSuccess;
     const size_t lds = (size_t)(SLOTS + SSCR + 256) * sizeof(unsigned long long);

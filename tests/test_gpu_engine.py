@@ -112,6 +112,32 @@ def test_groups_and_graph_replay_do_not_change_ids(E, oracle, tiny_weights, tiny
     eng.close()
 
 
+@pytest.mark.parametrize("switches", [{"T3_ZERO_COPY": "0"}, {"T3_PREFETCH": "0"}, {"T3_GEMM_SMALL_M": "0"},
+                                      {"T3_ZERO_COPY": "0", "T3_PREFETCH": "0", "T3_GEMM_SMALL_M": "0"}, {"T3_PREFETCH_DOWN_LINES": "1024"}])
+def test_transport_and_prefetch_switches_do_not_change_ids(E, oracle, tiny_weights, tiny_oracle, cond, switches, monkeypatch):
+    """How a step's metadata and ids travel (read / written in pinned host memory by the step's own kernels, or by copy kernels), whether
+    gate/up's epilogue waves fetch down_proj's weights into L2, and whether the few-row GEMM forms skip padded activation rows are
+    transport and scheduling only: with each of them switched off (the defaults are on and run in every other test) every stream --
+    1, 2 and 5 utterances at a time, graph replay with run-ahead, utterances that stop at different steps -- still equals its oracle stream."""
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=400, max_seqs=5, kv_bytes=1 << 29, enforce_eager=False)
+    eng.load_tensors(tiny_weights); eng.finalize()
+    rid = 0
+    for wave in (1, 2, 5):
+        reqs = []
+        for i in range(wave):
+            prompt = make_prompt(6 + 9 * i, seed=90 + rid)
+            kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=5, uid=rid, max_tokens=9 + 4 * i, ignore_eos=True)
+            reqs.append((rid, prompt, kw)); eng.add_request(rid, prompt, cond, E.make_sampling(**kw)); rid += 1
+        eng.run_until_done()
+        for r, prompt, kw in reqs:
+            got, _ = eng.get_output(r)
+            want, _ = tiny_oracle.generate(prompt, cond, oracle.make_sampling(**kw), max_model_len=400)
+            assert [t - 2500 for t in got] == want, f"utterance {r} with {switches}"
+    eng.close()
+
+
 @pytest.mark.parametrize("run_ahead", ["1", "0"])
 def test_run_ahead_with_stop_tokens(E, oracle, tiny_weights, tiny_oracle, cond, run_ahead, monkeypatch):
     """The C++ step loop schedules step N+1 before it has read step N's tokens (DESIGN.md "Run-ahead"): an utterance
