@@ -71,6 +71,7 @@ struct T3Engine {
     std::string err;
     hipStream_t stream = nullptr;     // admission copies (cond, sampling params, block table); groups wait on ev_admit
     hipEvent_t ev_admit = nullptr;
+    uint64_t admit_seq = 0;           // admissions recorded on ev_admit so far
     bool finalized = false;
     int max_blocks = 0;        // per stream
     int64_t n_blocks = 0;      // pool
@@ -109,6 +110,7 @@ struct T3Engine {
         size_t meta_bytes = 0, meta_rows_off = 0;
         Meta hm[2]{}, dm{};
         int* h_out_tok[2] = {nullptr, nullptr};
+        uint64_t waited_admit_seq = 0;     // the admission this group's stream has been ordered behind
         hipEvent_t ev_done[2] = {nullptr, nullptr};
         int rcap = 0;              // row budget per step
         std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;   // (M, n_sel, staging buffer) -> captured decode step
@@ -542,8 +544,10 @@ static int admit(T3Engine* e) {
         // r.cond / r.sp are kept alive in the request map until the copy is consumed (stream-ordered, pageable -> staged synchronously)
         e->running.push_back(r.id);
     }
-    (void)table_dirty;   // block ids reach the device inside the per-step row records
-    HIP_TRY(hipEventRecord(e->ev_admit, e->stream));
+    // block ids reach the device inside the per-step row records; the admission copies are ordered in front of the next step by an
+    // event, recorded (and waited for, enqueue_step) only when something was admitted: a cross-queue wait in front of EVERY step cost
+    // ~18 us of idle GPU between two steps (profiles/r03_c_step_timeline.json against r03_d)
+    if (table_dirty) { HIP_TRY(hipEventRecord(e->ev_admit, e->stream)); ++e->admit_seq; }
     e->st.kv_blocks_free = (int64_t)e->free_blocks.size();
     return T3_OK;
 }
@@ -755,7 +759,7 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
         const T3Engine::StepRec& sr = st.g[gi];
         if (sr.M == 0) continue;
         hipStream_t s = stream_of(gi);
-        HIP_TRY(hipStreamWaitEvent(s, e->ev_admit, 0));
+        if (g.waited_admit_seq != e->admit_seq) { HIP_TRY(hipStreamWaitEvent(s, e->ev_admit, 0)); g.waited_admit_seq = e->admit_seq; }
         if (!e->zero_copy) HIP_TRY(hipMemcpyAsync(g.d_meta, g.h_meta[buf], g.meta_rows_off + (size_t)sr.M * e->row_stride * 4, hipMemcpyHostToDevice, s));   // sel arrays + the used row records
         if (e->d_dbg_emb) {
             e->dbg_emb_rec.resize((size_t)2 * sr.M);

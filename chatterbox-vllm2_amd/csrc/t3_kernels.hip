@@ -1435,7 +1435,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
         rope8(*reinterpret_cast<const uint4*>(src + D + kg * 8), *reinterpret_cast<const uint4*>(src + D + 32 + kg * 8), c, s, knf[0], knf[1]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) vnew[dt] = src[2 * D + 16 * dt + col];
-#if defined(T3_ATTN_NOKVWRITE) || defined(T3_ATTN_K_TILE_WRITE)
+#if defined(T3_ATTN_NOKVWRITE) || defined(T3_ATTN_K_TILE_WRITE) || defined(T3_ATTN_NOKWRITE)
         if (false) {                                // NOKVWRITE: timing diagnostic only (the following steps read stale K / V); K_TILE_WRITE: K goes back from the chunk loop
 #else
         if (wave == 0) {                            // paged write of the newest K (8 pieces of 16 bytes, early: their latency hides under the tile stream)
@@ -1513,7 +1513,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
                 for (int dt = 0; dt < 4; ++dt) {
                     if (tss == 0) patch16(vf[2 * dt], js, vnew[dt]); else patch16(vf[2 * dt + 1], js, vnew[dt]);
                 }
-#if !defined(T3_ATTN_V_ELEMENT_WRITES) && !defined(T3_ATTN_NOKVWRITE)
+#if !defined(T3_ATTN_V_ELEMENT_WRITES) && !defined(T3_ATTN_NOKVWRITE) && !defined(T3_ATTN_NOVWRITE)
                 // Paged write of the newest V: V is stored token-minor (a lane's 16 bytes = 8 consecutive tokens of one dim), so one token is 64
                 // two-byte elements 16 bytes apart.  The patched pieces of this tile ARE the pool's content with the new token merged in: the 16
                 // lanes of the token's group write theirs back whole -- per dim tile 256 contiguous bytes (two full lines) instead of 16 partial
