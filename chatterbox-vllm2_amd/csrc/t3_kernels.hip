@@ -1351,7 +1351,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
     T3_ASTAMP(0);
     extern __shared__ __attribute__((aligned(16))) float part[];   // [max_chunks] m | [max_chunks] l | [max_chunks][64] o | per wave: 64 scores, 64 bf16 p | FUSE, per wave: [12][64] newest k / v
     float* pm = part; float* pl = part + a.max_chunks; float* po = part + 2 * a.max_chunks;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // EARLY (the 8-wave form = 1-4 utterances): the launch is a chain of dependent loads (kernel arguments -> row record -> block id -> tile
+    // -> arithmetic, 3.6 of its 5.6 us at B = 1), so (a) the wave index is made uniform for the compiler: block ids come by SCALAR loads, (b) the
+    // block of the wave's first chunk is asked for together with the context length, (c) the pre-RoPE q / k pieces, which need nothing from the
+    // record, are asked for before it has arrived, and the RoPE table rows before the tile.  B = 1: 1 318 -> 1 341 tok/s on one box.  At 64
+    // rows (4-wave form) the same order is 0.6 % SLOWER (the launch streams at the memory system's pace from its first microsecond; 21.18 ->
+    // 21.06 k tok/s, three alternating runs): the 4-wave form keeps the order of round 2.
+    constexpr bool EARLY = FUSE && NW == 8;
+    const int lane = threadIdx.x & 63, wave = EARLY ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
     float* sbuf = part + 66 * a.max_chunks + wave * 96;            // 64 floats of scores, then 64 bf16 (32 floats) of probabilities
     uint32_t* stash = reinterpret_cast<uint32_t*>(part + 66 * a.max_chunks + NW * 96) + wave * (12 * 64) + (threadIdx.x & 63);   // FUSE: the newest key / value park here
     uint16_t* pbuf = reinterpret_cast<uint16_t*>(sbuf + 64);
@@ -1370,12 +1377,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
         __syncthreads();                               // at entry: the waves of a workgroup start together, nothing is in flight yet
     }
     const int h = blockIdx.x, row = blockIdx.y;
+    const int col = lane & 15, kg = lane >> 4;
+    const uint16_t* src = FUSE ? a.qkv + (size_t)row * QKV + h * HD : nullptr;
+    uint4 qraw[2], kraw[2];
+    if constexpr (EARLY) {
+        qraw[0] = *reinterpret_cast<const uint4*>(src + kg * 8); qraw[1] = *reinterpret_cast<const uint4*>(src + 32 + kg * 8);
+        kraw[0] = *reinterpret_cast<const uint4*>(src + D + kg * 8); kraw[1] = *reinterpret_cast<const uint4*>(src + D + 32 + kg * 8);
+    }
     const int* rec = a.rowrec + (size_t)row * a.row_stride;
     const int L = rec[1] + 1;
     const int nc = (L + CHUNK - 1) / CHUNK;
-    const int col = lane & 15, kg = lane >> 4;
     const int* bt = rec + ROW_HDR;                 // the row's KV block ids travel with the row record
     constexpr int CPB = KV_BLOCK / CHUNK;          // chunks per physical block
+    // EARLY: before it is known whether the wave has a chunk at all (the word is inside the row record either way)
+    int blk_first = 0;
+    if constexpr (EARLY) {
+        blk_first = bt[wave / CPB];
+        asm volatile("" : "+s"(blk_first));         // hipcc would sink the load into the `wave < nc` branch, i.e. behind the wait for the context length
+    }
 
     uint4 kf[8], vf[8];                            // K fragments (tt, ds) at 2 tt + ds; V fragments (dt, ts) at 2 dt + ts
     // A chunk's tile is 8 K fragments (16 tokens x 32 dims each) + 8 V fragments (32 tokens x 16 dims each).  Of the context's LAST
@@ -1388,7 +1407,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
     constexpr bool PARTIAL = true;
 #endif
     auto load_tiles = [&](int c) {
-        const int blk = bt[c / CPB], ci = c % CPB;
+        const int blk = (EARLY && c == wave) ? blk_first : bt[c / CPB], ci = c % CPB;
         const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 0, h) + (size_t)ci * (CHUNK * HD)) + lane;
         const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 1, h) + (size_t)ci * (CHUNK * HD)) + lane;
         const int npool = L - (FUSE ? 1 : 0) - c * CHUNK;       // tokens of this chunk that live in the pool (wave-uniform; >= 64 except in the last chunk)
@@ -1413,8 +1432,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
         }
     };
 
-    // the wave's first K/V tile is requested before anything else so that the q / RoPE prologue overlaps its flight
-    if (wave < nc) load_tiles(wave);
+    // the wave's first K/V tile is requested before anything else so that the q / RoPE prologue overlaps its flight (EARLY: right behind the
+    // RoPE table rows, which are small and which the prologue needs first: loads retire in issue order)
+    if (!EARLY && wave < nc) load_tiles(wave);
     uint4 qfrag[2];                                 // B operand: q[32 ds + 8 kg .. +7], the same in all 16 columns
     uint4 knf[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};      // FUSE: the newest key in A-fragment form
     uint32_t vnew[4] = {0, 0, 0, 0};                // FUSE: the newest value, dims 16 dt + col
@@ -1422,17 +1442,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
         // RoPE of this head's q and k exactly as rope_kv_kernel does it (same products, same roundings): a lane holds
         // both halves of its rotation pairs (dims 8 kg + j and 32 + 8 kg + j), i.e. exactly its two operand fragments.
         const int pos = L - 1;
-        const uint16_t* src = a.qkv + (size_t)row * QKV + h * HD;
         float c[8], s[8];
         {
             const float4* cp = reinterpret_cast<const float4*>(a.cos_t + (size_t)pos * 32 + kg * 8);
             const float4* sp = reinterpret_cast<const float4*>(a.sin_t + (size_t)pos * 32 + kg * 8);
             const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+            if (EARLY && wave < nc) load_tiles(wave);
             c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
             s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
         }
-        rope8(*reinterpret_cast<const uint4*>(src + kg * 8), *reinterpret_cast<const uint4*>(src + 32 + kg * 8), c, s, qfrag[0], qfrag[1]);
-        rope8(*reinterpret_cast<const uint4*>(src + D + kg * 8), *reinterpret_cast<const uint4*>(src + D + 32 + kg * 8), c, s, knf[0], knf[1]);
+        if constexpr (EARLY) {
+            rope8(qraw[0], qraw[1], c, s, qfrag[0], qfrag[1]);
+            rope8(kraw[0], kraw[1], c, s, knf[0], knf[1]);
+        } else {
+            rope8(*reinterpret_cast<const uint4*>(src + kg * 8), *reinterpret_cast<const uint4*>(src + 32 + kg * 8), c, s, qfrag[0], qfrag[1]);
+            rope8(*reinterpret_cast<const uint4*>(src + D + kg * 8), *reinterpret_cast<const uint4*>(src + D + 32 + kg * 8), c, s, knf[0], knf[1]);
+        }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) vnew[dt] = src[2 * D + 16 * dt + col];
 #if defined(T3_ATTN_NOKVWRITE) || defined(T3_ATTN_K_TILE_WRITE) || defined(T3_ATTN_NOKWRITE)
