@@ -280,8 +280,8 @@ def dominant_kernel_roofline(prof, dom_only, args):
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algo_bytes_per_launch": round(algo), "avg_launch_ms": round(ms, 5), "launches": kern[dom][1],
-            "timing": "HIP events on the engine's stream around every launch of this kernel class in a pass of the same steps "
-                      "(an event pair costs ~2 us on top of the kernel; the rocprofv3 average of the same kernel is in profiles/README.md)"}
+            "timing": "HIP events on the engine's stream, as the start / stop events of every launch of this kernel class (hipExtLaunchKernelGGL: "
+                      "the dispatch's begin / end) in a pass of the same steps; the rocprofv3 average of the same kernel is in profiles/README.md"}
     return roof, {k: round(tot[k] / pst.decode_steps, 4) for k in tot}
 
 

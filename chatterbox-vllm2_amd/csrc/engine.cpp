@@ -560,9 +560,12 @@ struct Prof {
         auto& v = e->pev[k]; size_t& u = e->pev_used[k];
         if (u == v.size()) { hipEvent_t x, y; hipEventCreate(&x); hipEventCreate(&y); v.emplace_back(x, y); }
         a = v[u].first; b = v[u].second; ++u;
+        // the launch inside this scope takes the pair as its own start / stop events (the dispatch's begin / end, as rocprofv3 sees it);
+        // a launcher that does not (several kernels, the prefill schedules) leaves them armed and gets the bracketing records instead
         hipEventRecord(a, st);
+        arm_launch_events(a, b);
     }
-    ~Prof() { if (on) hipEventRecord(b, st); }
+    ~Prof() { if (on && launch_events_armed()) { arm_launch_events(nullptr, nullptr); hipEventRecord(b, st); } }
 };
 
 // One group's kernel sequence for one step, in phases (eager, or recorded into a hipGraph by the caller): embed | per layer: qkv,

@@ -1,6 +1,7 @@
 // Internal launcher interface between engine.cpp and t3_kernels.hip (not part of the C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/t3_engine.h"
@@ -138,6 +139,10 @@ struct SampleArgs {
     int* out_tok_host = nullptr;   // nullable: [n] in pinned host memory, written beside out_tok (no copy kernel behind the step)
 };
 hipError_t launch_sampler(const SampleArgs& a, hipStream_t s);
+// Profile mode: the next single-kernel launch of this thread (decode GEMM forms, fused / per-row attention, embed, sampler) takes these as
+// its start / stop events (hipExtLaunchKernelGGL); launch_events_armed() afterwards tells whether a launcher consumed them.
+void arm_launch_events(hipEvent_t start, hipEvent_t stop);
+bool launch_events_armed();
 hipError_t prepare_kernels();   // one-time function attributes (must run before any stream capture)
 hipError_t launch_expf(const float* x, float* y, int n, hipStream_t s);
 

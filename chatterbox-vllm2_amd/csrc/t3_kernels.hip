@@ -19,6 +19,22 @@
 #include <utility>
 
 namespace t3 {
+// Profile mode (engine.cpp: Prof): the NEXT single-kernel launch of this thread carries these two events as its start / stop events
+// (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps, what rocprofv3 reports), instead of being bracketed by two
+// hipEventRecord barrier packets, which add ~2-3 us of command-processor time to a 5-30 us kernel.
+static thread_local hipEvent_t g_arm_start = nullptr, g_arm_stop = nullptr;
+void arm_launch_events(hipEvent_t start, hipEvent_t stop) { g_arm_start = start; g_arm_stop = stop; }
+bool launch_events_armed() { return g_arm_start != nullptr; }
+template <typename F, typename... Args>
+static inline void launch_k(F kernel, const dim3& grid, const dim3& block, size_t lds, hipStream_t s, Args... args) {
+    if (g_arm_start) {
+        hipEvent_t a = g_arm_start, b = g_arm_stop;
+        g_arm_start = nullptr; g_arm_stop = nullptr;
+        hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, s, a, b, 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Skinny GEMM  y[m][n] = sum_k x[m][k] * W[n][k]   (x, W bf16, fp32 accumulation on the matrix cores)
@@ -902,7 +918,7 @@ static hipError_t launch_gemm2_av(const GemmArgs* a, hipStream_t s) {
     const int ntiles = a->packed_tiles > 0 ? a->packed_tiles / (EPI == EPI_SILU ? 2 : 1) : (a->N + 15) / 16;
     const int gx = (EPI == EPI_SILU) ? (ntiles + NT / 2 - 1) / (NT / 2) : (ntiles + NT - 1) / NT;
     const int gy = ((a->M + 15) / 16 + MT - 1) / MT;
-    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3((NW + gemm2_ew<NW>()) * 64), lds, s, *a);
+    launch_k(kern, dim3(gx, gy), dim3((NW + gemm2_ew<NW>()) * 64), lds, s, *a);
     return hipGetLastError();
 }
 // picks AV (see gemm2_kernel): the fewest A-row instructions that cover the rows of a one-tile call
@@ -947,7 +963,7 @@ static hipError_t launch_gemm2_loop_t(const GemmArgs* a, hipStream_t s) {
     if (split_env < 0) { const char* e = getenv(NW == 16 ? "T3_GEMM_LOOP16_SPLIT" : "T3_GEMM_LOOP_SPLIT"); split_env = e ? atoi(e) : 0; }
     int gy = split_env > 0 ? split_env : (NW == 16 ? (NT == 2 ? 8 : 4) : 2);
     while (gy > 1 && mgroups / gy < (NW == 16 ? 1 : 2)) --gy;      // 4 waves: every workgroup walks at least two groups (16 waves: one is enough to win, measured)
-    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NW * 64), lds, s, *a);
+    launch_k(kern, dim3(gx, gy), dim3(NW * 64), lds, s, *a);
     return hipGetLastError();
 }
 // NORM forms (4 waves, K = 1024): MT in {1, 2}, NT in {1, 2, 3, 4}
@@ -1168,7 +1184,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
 }
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(embed_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
+    launch_k(embed_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -2094,7 +2110,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     const dim3 grid(H, a.rows);
     const bool fuse = a.qkv != nullptr;
     const size_t lds = ((size_t)a.max_chunks * 66 + (size_t)(nw == 8 ? 8 : 4) * (96 + (fuse ? 12 * 64 : 0)) + 4) * sizeof(float);     // + the chunk counter
-#define T3_ATTN(NW, NTF, FU) hipLaunchKernelGGL((attention_kernel<NW, NTF, FU>), grid, dim3(NW * 64), lds, s, a)
+#define T3_ATTN(NW, NTF, FU) launch_k((attention_kernel<NW, NTF, FU>), grid, dim3(NW * 64), lds, s, a)
     if (nw == 8) { if (fuse) { if (nt) T3_ATTN(8, true, true); else T3_ATTN(8, false, true); } else { if (nt) T3_ATTN(8, true, false); else T3_ATTN(8, false, false); } }
     else { if (fuse) { if (nt) T3_ATTN(4, true, true); else T3_ATTN(4, false, true); } else { if (nt) T3_ATTN(4, true, false); else T3_ATTN(4, false, false); } }
 #undef T3_ATTN
@@ -2442,7 +2458,7 @@ hipError_t launch_sampler(const SampleArgs& a, hipStream_t s) {
     const size_t lds = (size_t)(SLOTS + SSCR + 256) * sizeof(unsigned long long);
     hipError_t e = prepare_kernels();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sampler_kernel, dim3(a.n), dim3(STH), lds, s, a);
+    launch_k(sampler_kernel, dim3(a.n), dim3(STH), lds, s, a);
     return hipGetLastError();
 }
 
