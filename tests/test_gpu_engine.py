@@ -138,6 +138,45 @@ def test_transport_and_prefetch_switches_do_not_change_ids(E, oracle, tiny_weigh
     eng.close()
 
 
+def test_profile_mode_times_every_class_and_changes_no_id(E, oracle, tiny_weights, tiny_oracle, cond):
+    """bench.py's roofline pass: in profile mode every decode-path launch carries two HIP events as its own start / stop events
+    (hipExtLaunchKernelGGL).  The ids must not change, every class must report one launch per layer and decode step (one per step for the
+    head, the sampler and the embed kernel), and a launch's duration must be a kernel's duration: above zero, far below a millisecond;
+    with events on ONE class only, the others report nothing."""
+    eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=400, max_seqs=3, kv_bytes=1 << 29, enforce_eager=False)
+    eng.load_tensors(tiny_weights); eng.finalize()
+    reqs = []
+    for i in range(3):
+        prompt = make_prompt(6 + 5 * i, seed=120 + i)
+        kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=9, uid=i, max_tokens=12, ignore_eos=True)
+        reqs.append((i, prompt, kw)); eng.add_request(i, prompt, cond, E.make_sampling(**kw))
+    while eng.stats().decode_steps == 0 or eng.stats().prefill_rows < sum(2 * len(p) for _, p, _ in reqs):
+        eng.step()                                      # every prompt prefilled: what follows are decode-only steps
+    eng.reset_stats(); eng.set_profile(True)
+    eng.run_steps(5)
+    steps = eng.stats().decode_steps
+    assert steps == 5
+    per_layer = {"gemm_qkv", "gemm_o", "gemm_gateup", "gemm_down", "attention"}
+    for k in E.KERNEL_CLASSES:
+        ms, n = eng.kernel_ms(k)
+        want = 0 if k == "rope_kv" else (2 * steps if k in per_layer else steps)
+        assert n == want, f"{k}: {n} launches timed, expected {want}"
+        if n:
+            assert 0.0005 < ms < 0.5, f"{k}: {ms} ms per launch"
+    eng.reset_stats(); eng.set_profile(True, only="attention")
+    eng.run_steps(3)
+    for k in E.KERNEL_CLASSES:
+        ms, n = eng.kernel_ms(k)
+        assert (n == 6 and 0.0005 < ms < 0.5) if k == "attention" else n == 0, f"{k}: {n} launches, {ms} ms with events on the attention only"
+    eng.set_profile(False)
+    eng.run_until_done()
+    for i, prompt, kw in reqs:
+        got, _ = eng.get_output(i)
+        want, _ = tiny_oracle.generate(prompt, cond, oracle.make_sampling(**kw), max_model_len=400)
+        assert [t - 2500 for t in got] == want, f"utterance {i}"
+    eng.close()
+
+
 @pytest.mark.parametrize("run_ahead", ["1", "0"])
 def test_run_ahead_with_stop_tokens(E, oracle, tiny_weights, tiny_oracle, cond, run_ahead, monkeypatch):
     """The C++ step loop schedules step N+1 before it has read step N's tokens (DESIGN.md "Run-ahead"): an utterance
