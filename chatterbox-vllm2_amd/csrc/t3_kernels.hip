@@ -63,6 +63,7 @@ __device__ unsigned long long g_gemm_clk[8][2048][5];
 // gemm2_kernel (the current decode schedule): class 0 qkv / head, 1 gate/up, 2 o, 3 down; stamps: 0 entry, 1 A rows landed and staged
 // in LDS, 2 first weight k-block landed, 3 last MFMA issued, 4 partials exchanged (barrier passed), 5 outputs stored
 __device__ unsigned long long g_gemm2_clk[4][2048][6];
+extern "C" int t3_debug_gemm2_clk(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm2_clk), sizeof(g_gemm2_clk)); }
 #define T3_G2STAMP(i) do { if (threadIdx.x == 0) g_gemm2_clk[NORM ? (EPI == EPI_SILU ? 1 : 0) : (KBS == 2 ? 2 : 3)][(blockIdx.y * gridDim.x + blockIdx.x) & 2047][i] = wall_clock64(); } while (0)
 #else
 #define T3_GSTAMP(i)
@@ -1408,7 +1409,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
     // EARLY: before it is known whether the wave has a chunk at all (the word is inside the row record either way)
     int blk_first = 0;
     if constexpr (EARLY) {
-        blk_first = bt[wave / CPB];
+        blk_first = __builtin_amdgcn_readfirstlane(bt[wave / CPB]);      // uniform already; says so to every build (the stamped one kept it in a VGPR)
         asm volatile("" : "+s"(blk_first));         // hipcc would sink the load into the `wave < nc` branch, i.e. behind the wait for the context length
     }
 
