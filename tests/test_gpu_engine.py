@@ -93,14 +93,14 @@ def test_batch_invariance_and_continuous_batching(E, oracle, tiny_engine, tiny_o
     assert st.kv_blocks_free == st.kv_blocks_total      # every block returned
 
 
-@pytest.mark.parametrize("n_groups,eager", [(1, True), (1, False), (3, False), (4, True)])
+@pytest.mark.parametrize("n_groups,eager", [(1, True), (3, False), (4, True)])        # (1, False) is every other test's configuration
 def test_groups_and_graph_replay_do_not_change_ids(E, oracle, tiny_weights, tiny_oracle, cond, n_groups, eager):
     """Concurrent utterance groups (separate streams) and hipGraph replay are scheduling only: every stream still
     equals its single-utterance oracle stream.  Requests finish at different steps, so graphs are re-captured."""
     eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=400, max_seqs=6, kv_bytes=1 << 29, n_groups=n_groups, enforce_eager=eager)
     eng.load_tensors(tiny_weights); eng.finalize()
     reqs = []
-    for i in range(9):
+    for i in range(7):
         prompt = make_prompt(5 + 7 * i, seed=40 + i)
         kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=3, uid=i, max_tokens=6 + 5 * (i % 4), ignore_eos=True)
         reqs.append((i, prompt, kw)); eng.add_request(i, prompt, cond, E.make_sampling(**kw))
@@ -185,11 +185,11 @@ def test_run_ahead_with_stop_tokens(E, oracle, tiny_weights, tiny_oracle, cond, 
     eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=400, max_seqs=4, kv_bytes=1 << 29, enforce_eager=False)
     eng.load_tensors(tiny_weights); eng.finalize()
     reqs = []
-    for i in range(7):
+    for i in range(6):
         prompt = make_prompt(4 + 5 * i, seed=70 + i)
-        kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=11, uid=i, max_tokens=22)
+        kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=11, uid=i, max_tokens=20)
         ref, _ = tiny_oracle.generate(prompt, cond, oracle.make_sampling(ignore_eos=True, **kw), max_model_len=400)
-        stop = ref[3 + 3 * i] if i < 6 else 8193       # stops at different steps; the last one runs into max_tokens
+        stop = ref[3 + 3 * i] if i < 5 else 8193       # stops at different steps; the last one runs into max_tokens
         want, _ = tiny_oracle.generate(prompt, cond, oracle.make_sampling(stop_token=stop, **kw), max_model_len=400)
         assert want == ref[: ref.index(stop) + 1] if stop in ref else want == ref
         reqs.append((i, want, 1 if stop in ref else 2))
@@ -339,8 +339,8 @@ def test_llm_surface(E, oracle, tiny_oracle, cond, tmp_path):
     assert ids[0] == 255 and ids[-1] == 0 and ids.count(2) == 2
     sp = SamplingParams(temperature=0.8, stop_token_ids=[6562 + 2500], max_tokens=min(1000, 240), top_p=0.8, repetition_penalty=2.0)   # tts.py:455-464
     u0 = llm._next_uid                                        # unseeded requests take consecutive RNG streams
-    res = llm.generate([{"prompt": text, "multi_modal_data": mm}] * 3, sampling_params=sp)
-    assert len(res) == 3
+    res = llm.generate([{"prompt": text, "multi_modal_data": mm}] * 2, sampling_params=sp)
+    assert len(res) == 2
     for k, r in enumerate(res):
         want, _ = tiny_oracle.generate(assemble_prompt_ids(ids), cond, oracle.make_sampling(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, uid=u0 + k,
                                                                                           max_tokens=240), max_model_len=240)
