@@ -1203,15 +1203,26 @@ __device__ __forceinline__ void rope8(const uint4& x1, const uint4& x2, const fl
     o2.x = pack2(r2[0], r2[1]); o2.y = pack2(r2[2], r2[3]); o2.z = pack2(r2[4], r2[5]); o2.w = pack2(r2[6], r2[7]);
 }
 // Paged KV layout of one (block, head): [chunk-in-block (KV_BLOCK/64)][8 fragments][64 lanes][8 bf16] for K and for V.
-//   K fragment (tt, ds), lane t + 16 kg, element j  =  K[token 16 tt + t of the chunk][dim 32 ds + 8 kg + j]    (MFMA A operand: rows = tokens)
+//   K fragment (tt, ds), lane t + 16 kg, element j  =  K[token 16 tt + t of the chunk][dim 32 ds + 8 kg + j]    (MFMA A operand: rows = tokens);
+//     in MEMORY the lane's 16-byte piece sits at piece index 4 t + kg of the fragment (token-major: k_piece() below)
 //   V fragment (dt, ts), lane d + 16 kg, element j  =  V[token 32 ts + 8 kg + j of the chunk][dim 16 dt + d]    (MFMA A operand: rows = dims)
 // so the attention kernel feeds v_mfma_f32_16x16x32_bf16 straight from fully coalesced 1 KiB wave loads.
 __device__ __forceinline__ size_t kv_head_base(int blk, int kv, int h) {
     return (size_t)blk * KV_BLOCK_ELEMS + (size_t)(kv * H + h) * KV_HEAD_ELEMS;
 }
+// Where the 16-byte piece of lane (token t, dim slice kg) sits inside a K fragment's 1 KiB: token-major (4 t + kg), so that a token's four
+// slices are 64 contiguous bytes and the newest token's K write touches 2 lines per (row, head).  In lane order (t + 16 kg: the MFMA A
+// operand's own order, rounds 1-3, -DT3_K_TOKEN_MAJOR=0) they are 256 bytes apart, 8 lines per (row, head), and the write's cost follows the
+// lines touched: C3 21.12 -> 21.27 k tok/s (profiles/r03_k_token_major_*.json).  A wave still loads the same 1 KiB per fragment, each lane
+// from its permuted place.  Every K reader and writer goes through k_piece() / k_lane_piece().
+#ifndef T3_K_TOKEN_MAJOR
+#define T3_K_TOKEN_MAJOR 1
+#endif
+__device__ __forceinline__ int k_piece(int t, int kg) { return T3_K_TOKEN_MAJOR ? 4 * t + kg : t + 16 * kg; }
+__device__ __forceinline__ int k_lane_piece(int lane) { return T3_K_TOKEN_MAJOR ? 4 * (lane & 15) + (lane >> 4) : lane; }      // the piece lane (t = lane % 16, kg = lane / 16) loads
 __device__ __forceinline__ size_t k_slot(int tok_in_block, int ds, int kg) {      // start of the 8-element (16 B) piece
     const int ci = tok_in_block / CHUNK, tc = tok_in_block % CHUNK;
-    return (size_t)ci * (CHUNK * HD) + (size_t)((tc >> 4) * 2 + ds) * 512 + (size_t)((tc & 15) + 16 * kg) * 8;
+    return (size_t)ci * (CHUNK * HD) + (size_t)((tc >> 4) * 2 + ds) * 512 + (size_t)k_piece(tc & 15, kg) * 8;
 }
 __device__ __forceinline__ size_t v_elem(int tok_in_block, int dim) {              // one bf16
     const int ci = tok_in_block / CHUNK, tc = tok_in_block % CHUNK;
@@ -1425,7 +1436,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
 #endif
     auto load_tiles = [&](int c) {
         const int blk = (EARLY && c == wave) ? blk_first : bt[c / CPB], ci = c % CPB;
-        const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 0, h) + (size_t)ci * (CHUNK * HD)) + lane;
+        const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 0, h) + (size_t)ci * (CHUNK * HD)) + k_lane_piece(lane);
         const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 1, h) + (size_t)ci * (CHUNK * HD)) + lane;
         const int npool = L - (FUSE ? 1 : 0) - c * CHUNK;       // tokens of this chunk that live in the pool (wave-uniform; >= 64 except in the last chunk)
         if (!PARTIAL || npool >= CHUNK) {
@@ -1716,7 +1727,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void qkv_in_attention_ker
     uint4 kf[8], vf[8];
     auto load_tiles = [&](int c) {
         const int blk = bt[c / CPB], ci = c % CPB;
-        const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 0, h) + (size_t)ci * (CHUNK * HD)) + lane;
+        const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 0, h) + (size_t)ci * (CHUNK * HD)) + k_lane_piece(lane);
         const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 1, h) + (size_t)ci * (CHUNK * HD)) + lane;
         const int npool = L - 1 - c * CHUNK;
         if (npool >= CHUNK) {
@@ -1995,7 +2006,7 @@ __global__ __launch_bounds__(256, 2) void attention_tile_kernel(AttnArgs a, int 
             uint4 kf[8], vf[8];
             {
                 const int blk = bt[c / CPB], ci = c % CPB;
-                const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 0, h) + (size_t)ci * (CHUNK * HD)) + lane;
+                const uint4* Kp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 0, h) + (size_t)ci * (CHUNK * HD)) + k_lane_piece(lane);
                 const uint4* Vp = reinterpret_cast<const uint4*>(a.kv_layer + kv_head_base(blk, 1, h) + (size_t)ci * (CHUNK * HD)) + lane;
 #pragma unroll
                 for (int f = 0; f < 8; ++f) kf[f] = Kp[f * 64];
