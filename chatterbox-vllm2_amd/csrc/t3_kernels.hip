@@ -1549,6 +1549,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
                 kf[2 * tt + 1].z = hit ? knf[1].z : kf[2 * tt + 1].z; kf[2 * tt + 1].w = hit ? knf[1].w : kf[2 * tt + 1].w;
             }
 #if defined(T3_ATTN_K_TILE_WRITE) && !defined(T3_ATTN_NOKVWRITE)
+            static_assert(!T3_K_TOKEN_MAJOR, "the K tile write-back variant was written for lane-order K fragments (-DT3_K_TOKEN_MAJOR=0)");
             // Diagnostic variant: the newest K written back from the patched tile as full lines (the lanes of the token's aligned 8-token group,
             // per (dim half, dim octet) 128 contiguous bytes) instead of 8 pieces of 16 bytes from the prologue.  Bit-exact and 0.3 % SLOWER at C3
             // (20.48 against 20.54 k tok/s): these stores come late in the workgroup's life and their latency is no longer hidden.
