@@ -82,7 +82,6 @@ struct T3Engine {
     int prefetch_down_lines = 768;    // T3_PREFETCH_DOWN_LINES: 128-byte lines of every down_proj tile (1024) the gate/up launch fetches
     bool zero_copy = true;            // T3_ZERO_COPY=0: the step's metadata / sampled ids travel by hipMemcpyAsync (two copy kernels per step) instead of being read / written in pinned host memory by the step's own kernels
     int prefetch = 1;                 // T3_PREFETCH=0: gate/up's epilogue waves do not fetch down_proj's weights into L2
-    bool qkv_in_attn = false;         // T3_QKV_IN_ATTN=1: decode-only steps run the qkv projection inside the attention launch (units + flags, t3_kernels.hip)
 
     // weights (device)
     std::vector<LayerW> layers;
@@ -98,13 +97,12 @@ struct T3Engine {
     int* d_block_table = nullptr;
     std::vector<int> h_block_table;
 
-    // utterance groups: each group owns a stream, activation buffers, step metadata and captured graphs, so that
-    // one group's HBM-bound attention overlaps another group's latency-bound GEMM chain on the same GPU
+    // utterance groups: each group owns a stream, activation buffers, step metadata and captured graphs (measured: kernels of two
+    // streams do not overlap usefully on this part, profiles/NOTES.md; one group is the default)
     struct Meta { int* sel_rows; int4* sel; int* rows; int* out_tok; };   // sel arrays first, then the row records (one contiguous upload)
     struct Group {
         hipStream_t stream = nullptr;
         uint16_t *h = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *act = nullptr, *logits = nullptr;
-        unsigned* sync = nullptr; int sync_stride = 0;      // per layer: ticket / flags of the qkv-in-attention launch (zeroed by the step's embed kernel)
         float* rstd = nullptr;     // row statistic of the prefill-sized NORM GEMMs
         char *h_meta[2] = {nullptr, nullptr}, *d_meta = nullptr;     // host staging is double-buffered: step N+1 is built while N runs
         size_t meta_bytes = 0, meta_rows_off = 0;
@@ -129,15 +127,6 @@ struct T3Engine {
         std::chrono::steady_clock::time_point t_begin;
     };
     std::vector<Group> groups;
-    // Two-track ("antiphase") decode steps: with two utterance groups a decode-only step is ONE graph in which the groups' kernel chains
-    // run on parallel branches, and the HBM-bound attention launches alternate between them (A(L) -> B(L) -> A(L+1) ...): while one
-    // track's attention streams its K/V, the other track's latency-bound GEMM chain runs beside it.  Everything of a step is ordered on
-    // groups[0].stream; the second branch joins it inside the graph.
-    bool antiphase = false;
-    hipStream_t side_stream = nullptr;                   // the second track's branch
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    std::vector<hipEvent_t> ev_att;                      // [layer][track]: that track's attention of that layer has finished
-    std::map<std::array<int, 5>, hipGraphExec_t> graphs2;   // (M0, n_sel0, M1, n_sel1, staging buffer) -> captured two-track decode step
     unsigned step_seq = 0;
     bool run_ahead = true;     // t3_run_steps / t3_run_until_done enqueue step N+1 before reading step N's tokens
     int64_t graph_captures = 0; double graph_capture_ms = 0;      // T3_GRAPH_STATS=1 prints them at destroy
@@ -215,13 +204,10 @@ extern "C" int t3_create(const T3EngineConfig* cfg, T3Handle* out) {
         e->n_groups = std::max(1, std::min(g, std::min(8, cfg->max_seqs)));
         e->groups.resize(e->n_groups);
         if (const char* ev = getenv("T3_FUSE_ROPE")) e->fuse_rope = atoi(ev) != 0;
-        if (const char* ev = getenv("T3_QKV_IN_ATTN")) e->qkv_in_attn = atoi(ev) != 0;
         if (const char* ev = getenv("T3_PREFETCH")) e->prefetch = atoi(ev);
         if (const char* ev = getenv("T3_ZERO_COPY")) e->zero_copy = atoi(ev) != 0;
         if (const char* ev = getenv("T3_PREFETCH_DOWN_LINES")) e->prefetch_down_lines = atoi(ev);
         if (const char* ev = getenv("T3_RUN_AHEAD")) e->run_ahead = atoi(ev) != 0;
-        e->antiphase = e->n_groups == 2;
-        if (const char* ev = getenv("T3_ANTIPHASE")) e->antiphase = atoi(ev) != 0 && e->n_groups == 2;
     }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail_create(T3_E_DEVICE, "hipStreamCreate failed"); }
     hipEventCreate(&e->ev0); hipEventCreate(&e->ev1); hipEventCreateWithFlags(&e->ev_admit, hipEventDisableTiming);
@@ -245,7 +231,6 @@ extern "C" int t3_destroy(T3Handle e) {
     for (auto& g : e->groups) {
         if (g.stream) (void)hipStreamSynchronize(g.stream);
         for (auto& kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
-        free_dev(g.sync);
         free_dev(g.h); free_dev(g.qkv); free_dev(g.qrot); free_dev(g.att); free_dev(g.act); free_dev(g.logits); free_dev(g.rstd);
         free_dev(g.d_meta); free_dev(g.dm.out_tok);
         for (int b = 0; b < 2; ++b) {
@@ -255,11 +240,6 @@ extern "C" int t3_destroy(T3Handle e) {
         }
         if (g.stream) (void)hipStreamDestroy(g.stream);
     }
-    for (auto& kv : e->graphs2) (void)hipGraphExecDestroy(kv.second);
-    for (auto ev : e->ev_att) (void)hipEventDestroy(ev);
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
     free_dev(e->d_cond); free_dev(e->d_counts); free_dev(e->d_sp); free_dev(e->d_dbg); free_dev(e->d_hist);
     for (void* b : e->out_slabs) free_dev(b);      // every hand-off buffer (pooled or held by a request) lives in one of these
     free_dev(e->d_handoff_items); free_dev(e->d_dbg_emb);
@@ -417,8 +397,6 @@ extern "C" int t3_finalize_weights(T3Handle e) {
         if ((rc = dalloc(e, &g.act, R * F, true))) return rc;
         if ((rc = dalloc(e, &g.logits, 2 * Sg * VPAD, true))) return rc;
         if ((rc = dalloc(e, &g.rstd, R, true))) return rc;
-        g.sync_stride = (qkv_in_attention_sync_words((int)(2 * Sg)) + 15) & ~15;
-        if ((rc = dalloc(e, &g.sync, (size_t)e->cfg.n_layers * g.sync_stride, true))) return rc;
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
         const size_t o_selr = carve(2 * Sg * 4), o_sel = carve(Sg * 16), o_rows = carve(R * (size_t)e->row_stride * 4);
@@ -446,12 +424,6 @@ extern "C" int t3_finalize_weights(T3Handle e) {
     if (e->cfg.debug_logits && (rc = dalloc(e, &e->d_dbg, S * V, true))) return rc;
     if (e->cfg.debug_logits && e->n_groups == 1 && (rc = dalloc(e, &e->d_dbg_emb, (size_t)e->groups[0].rcap * D, true))) return rc;
     HIP_TRY(hipEventCreateWithFlags(&e->ev_handoff, hipEventDisableTiming));
-    if (e->antiphase) {
-        HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-        e->ev_att.resize((size_t)2 * e->cfg.n_layers);
-        for (auto& ev : e->ev_att) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
     if ((rc = dalloc(e, &e->d_hist, S * (size_t)e->cfg.max_model_len, true))) return rc;
     e->h_block_table.assign(2 * S * e->max_blocks, 0);
     HIP_TRY(t3::prepare_kernels());
@@ -570,10 +542,6 @@ struct Prof {
 
 // One group's kernel sequence for one step, in phases (eager, or recorded into a hipGraph by the caller): embed | per layer: qkv,
 // attention (RoPE / KV write fused for decode rows), o + gate/up + down | head + sampler.
-static bool step_fuses_qkv(const T3Engine* e, const T3Engine::StepRec& sr) {
-    return e->qkv_in_attn && e->fuse_rope && sr.n_prefill_rows == 0 && sr.M >= 2 && sr.M <= 2 * ((e->cfg.max_seqs + e->n_groups - 1) / e->n_groups) &&
-           qkv_in_attention_fits(sr.M, (e->cfg.max_model_len + CHUNK - 1) / CHUNK);
-}
 static int launch_embed_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int buf, hipStream_t s) {
     Prof p(e, K_EMBED, s);
     EmbedArgs ea{g.dm.rows, e->row_stride, e->d_cond, e->text_emb, e->text_pos, e->speech_emb, e->speech_pos, g.h, sr.M, g.dm.out_tok};
@@ -582,7 +550,6 @@ static int launch_embed_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::S
         ea.meta_vec = (int)((g.meta_rows_off + (size_t)sr.M * e->row_stride * 4) / 16);
         ea.host_rowrec = g.hm[buf].rows;
     }
-    if (step_fuses_qkv(e, sr)) { ea.zero_words = g.sync; ea.n_zero = e->cfg.n_layers * g.sync_stride; }
     HIP_TRY(launch_embed(ea, s));
     if (e->d_dbg_emb) HIP_TRY(hipMemcpyAsync(e->d_dbg_emb, g.h, (size_t)sr.M * D * 2, hipMemcpyDeviceToDevice, s));
     return T3_OK;
@@ -620,15 +587,6 @@ static int launch_attention_phase(T3Engine* e, T3Engine::Group& g, const T3Engin
     }
     return T3_OK;
 }
-// decode-only steps: the qkv projection runs INSIDE the attention launch (units taken by ticket, flags; qkv_in_attention_kernel)
-static int launch_qkv_attention_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int L, hipStream_t s) {
-    const size_t layer_elems = (size_t)e->n_blocks * KV_BLOCK_ELEMS;
-    uint16_t* kvL = e->kv + (size_t)L * layer_elems;
-    Prof p(e, K_ATTN, s);
-    AttnArgs aa{nullptr, kvL, g.dm.rows, e->row_stride, g.att, sr.M, (e->cfg.max_model_len + CHUNK - 1) / CHUNK, g.qkv, kvL, e->cos_t, e->sin_t};
-    HIP_TRY(launch_qkv_in_attention(g.h, (const uint4*)e->layers[L].qkv, g.qkv, g.sync + (size_t)L * g.sync_stride, aa, s));
-    return T3_OK;
-}
 static int launch_mlp_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int L, hipStream_t s) {
     LayerW& y = e->layers[L];
     const int M = sr.M;
@@ -655,41 +613,13 @@ static int launch_sample_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::
 static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec& sr, int buf, hipStream_t s) {
     int rc;
     if ((rc = launch_embed_phase(e, g, sr, buf, s))) return rc;
-    const bool fused_qkv = step_fuses_qkv(e, sr);
     for (int L = 0; L < e->cfg.n_layers; ++L) {
-        if (fused_qkv) {
-            if ((rc = launch_qkv_attention_phase(e, g, sr, L, s))) return rc;
-        } else {
-            if ((rc = launch_qkv_phase(e, g, sr, L, s))) return rc;
-            if ((rc = launch_attention_phase(e, g, sr, L, s))) return rc;
-        }
+        if ((rc = launch_qkv_phase(e, g, sr, L, s))) return rc;
+        if ((rc = launch_attention_phase(e, g, sr, L, s))) return rc;
         if ((rc = launch_mlp_phase(e, g, sr, L, s))) return rc;
     }
     return launch_sample_phase(e, g, sr, buf, s);
 }
-// The two-track schedule of a decode-only step (T3Engine::antiphase): track 0 on `s0`, track 1 on the side stream, forked from and
-// joined back into s0; the attention launches pass a token A(0) -> B(0) -> A(1) -> B(1) ... so that at any time at most one track
-// is in its HBM-bound phase and the other one's GEMM chain (a few MB per launch, latency-bound) runs beside it.
-static int launch_step_two_tracks(T3Engine* e, const T3Engine::Step& st, hipStream_t s0) {
-    hipStream_t ss[2] = {s0, e->side_stream};
-    int rc;
-    HIP_TRY(hipEventRecord(e->ev_fork, s0));
-    HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
-    for (int t = 0; t < 2; ++t) if ((rc = launch_embed_phase(e, e->groups[t], st.g[t], st.buf, ss[t]))) return rc;
-    for (int L = 0; L < e->cfg.n_layers; ++L)
-        for (int t = 0; t < 2; ++t) {
-            if ((rc = launch_qkv_phase(e, e->groups[t], st.g[t], L, ss[t]))) return rc;
-            if (L > 0 || t > 0) HIP_TRY(hipStreamWaitEvent(ss[t], t == 0 ? e->ev_att[2 * (L - 1) + 1] : e->ev_att[2 * L], 0));
-            if ((rc = launch_attention_phase(e, e->groups[t], st.g[t], L, ss[t]))) return rc;
-            HIP_TRY(hipEventRecord(e->ev_att[2 * L + t], ss[t]));
-            if ((rc = launch_mlp_phase(e, e->groups[t], st.g[t], L, ss[t]))) return rc;
-        }
-    for (int t = 0; t < 2; ++t) if ((rc = launch_sample_phase(e, e->groups[t], st.g[t], st.buf, ss[t]))) return rc;
-    HIP_TRY(hipEventRecord(e->ev_join, e->side_stream));
-    HIP_TRY(hipStreamWaitEvent(s0, e->ev_join, 0));
-    return T3_OK;
-}
-
 // Schedule one step and put it on the streams.  Does not wait for anything: a decode row whose input token is still
 // being sampled by the previous step refers to it by its index in the sampler's output array (EMB_SPEECH_PREV).
 static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
@@ -753,22 +683,18 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
     st.t_begin = std::chrono::steady_clock::now();
     if (st.M_all == 0) return T3_OK;
 
-    // antiphase engines order every step on groups[0].stream (the second track is a branch inside the step)
-    auto stream_of = [&](int gi) { return e->antiphase ? e->groups[0].stream : e->groups[gi].stream; };
     const bool graphs_ok = !e->cfg.enforce_eager && !e->profile && st.n_prefill_rows == 0;
-    const bool two_tracks = e->antiphase && st.n_prefill_rows == 0 && st.g[0].M > 0 && st.g[1].M > 0;
     for (int gi = 0; gi < e->n_groups; ++gi) {
         T3Engine::Group& g = e->groups[gi];
         const T3Engine::StepRec& sr = st.g[gi];
         if (sr.M == 0) continue;
-        hipStream_t s = stream_of(gi);
+        hipStream_t s = g.stream;
         if (g.waited_admit_seq != e->admit_seq) { HIP_TRY(hipStreamWaitEvent(s, e->ev_admit, 0)); g.waited_admit_seq = e->admit_seq; }
         if (!e->zero_copy) HIP_TRY(hipMemcpyAsync(g.d_meta, g.h_meta[buf], g.meta_rows_off + (size_t)sr.M * e->row_stride * 4, hipMemcpyHostToDevice, s));   // sel arrays + the used row records
         if (e->d_dbg_emb) {
             e->dbg_emb_rec.resize((size_t)2 * sr.M);
             for (int r = 0; r < sr.M; ++r) { const int* rec = g.hm[buf].rows + (size_t)r * e->row_stride; e->dbg_emb_rec[2 * r] = rec[0]; e->dbg_emb_rec[2 * r + 1] = rec[1]; }
         }
-        if (two_tracks) continue;                        // launched below, both tracks in one go
         if (graphs_ok) {
             const auto key = std::make_tuple(sr.M, sr.n_sel, e->zero_copy ? buf : 0);      // zero-copy: the pinned buffers of `buf` are kernel arguments
             auto it = g.graphs.find(key);
@@ -797,40 +723,6 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
         }
         if (sr.n_sel > 0 && !e->zero_copy) HIP_TRY(hipMemcpyAsync(g.h_out_tok[buf], g.dm.out_tok, (size_t)sr.n_sel * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(g.ev_done[buf], s));
-    }
-    if (two_tracks) {
-        hipStream_t s = e->groups[0].stream;
-        if (graphs_ok) {
-            const std::array<int, 5> key{st.g[0].M, st.g[0].n_sel, st.g[1].M, st.g[1].n_sel, e->zero_copy ? buf : 0};
-            auto it = e->graphs2.find(key);
-            if (it == e->graphs2.end()) {
-                hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-                const auto tc0 = std::chrono::steady_clock::now();
-                HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                const int lrc = launch_step_two_tracks(e, st, s);
-                const hipError_t ce = hipStreamEndCapture(s, &graph);
-                if (lrc) return lrc;
-                HIP_TRY(ce);
-                HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-                (void)hipGraphDestroy(graph);
-                if (e->graphs2.size() > 64) {
-                    HIP_TRY(hipStreamSynchronize(s));
-                    for (auto& kv : e->graphs2) (void)hipGraphExecDestroy(kv.second);
-                    e->graphs2.clear();
-                }
-                it = e->graphs2.emplace(key, exec).first;
-                ++e->graph_captures; e->graph_capture_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
-            }
-            HIP_TRY(hipGraphLaunch(it->second, s));
-        } else {
-            int lrc;
-            if ((lrc = launch_step_two_tracks(e, st, s))) return lrc;
-        }
-        for (int gi = 0; gi < 2; ++gi) {
-            T3Engine::Group& g = e->groups[gi];
-            if (st.g[gi].n_sel > 0 && !e->zero_copy) HIP_TRY(hipMemcpyAsync(g.h_out_tok[buf], g.dm.out_tok, (size_t)st.g[gi].n_sel * 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipEventRecord(g.ev_done[buf], s));
-        }
     }
     return T3_OK;
 }
@@ -900,14 +792,14 @@ static int complete_step(T3Engine* e, T3Engine::Step& st, T3StepResult* res) {
                     }
                     if (!e->out_pool.empty()) {
                         r.d_out = e->out_pool.back(); e->out_pool.pop_back();
-                        const hipError_t ce = hipMemcpyAsync(r.d_out, e->d_hist + (size_t)r.slot * e->cfg.max_model_len, r.out.size() * 4, hipMemcpyDeviceToDevice, e->antiphase ? e->groups[0].stream : e->groups[gi].stream);
+                        const hipError_t ce = hipMemcpyAsync(r.d_out, e->d_hist + (size_t)r.slot * e->cfg.max_model_len, r.out.size() * 4, hipMemcpyDeviceToDevice, e->groups[gi].stream);
                         if (ce != hipSuccess && !dev_rc) dev_rc = e->fail(T3_E_DEVICE, std::string("hand-off copy of a finished utterance's ids failed: ") + hipGetErrorString(ce));
                     }
                 }
                 if (res->n_finished < 64) res->finished_ids[res->n_finished] = r.id;
                 res->n_finished++;
                 e->finished_q.push_back(r.id);
-                if (e->finished_q.size() > (size_t)(4 * e->cfg.max_seqs + 4096)) e->finished_q.pop_front();     // a caller that never pops (LLM.generate reads outputs by id) must not grow it
+                if (e->finished_q.size() > (size_t)(4 * e->cfg.max_seqs + 4096)) { e->finished_q.pop_front(); e->st.finished_dropped++; }     // a caller that never pops (LLM.generate reads outputs by id) must not grow it
                 if (r.n_sched > (int)r.out.size()) r.zombie = true;     // the step running ahead still uses its slot and KV blocks
                 else release_slot(e, r);
             }
@@ -1094,8 +986,8 @@ extern "C" int t3_debug_logits(T3Handle e, int64_t req_id, float* out) {
 extern "C" int t3_stats(T3Handle e, T3Stats* out) { if (!e || !out) return T3_E_INVALID; *out = e->st; return T3_OK; }
 extern "C" int t3_reset_stats(T3Handle e) {
     if (!e) return T3_E_INVALID;
-    const int64_t bt = e->st.kv_blocks_total, bf = e->st.kv_blocks_free, wb = e->st.weight_bytes;
-    e->st = T3Stats{}; e->st.kv_blocks_total = bt; e->st.kv_blocks_free = bf; e->st.weight_bytes = wb;
+    const int64_t bt = e->st.kv_blocks_total, bf = e->st.kv_blocks_free, wb = e->st.weight_bytes, fd = e->st.finished_dropped;
+    e->st = T3Stats{}; e->st.kv_blocks_total = bt; e->st.kv_blocks_free = bf; e->st.weight_bytes = wb; e->st.finished_dropped = fd;
     for (int k = 0; k < K_COUNT; ++k) { e->k_ms[k] = 0; e->k_n[k] = 0; }
     return T3_OK;
 }

@@ -36,7 +36,7 @@ extern "C" int t3k_set_prefill_rows(int32_t rows) { set_pgemm_min_rows(rows); re
 extern "C" int t3k_set_prefill_wide_rows(int32_t rows) { set_pgemm_wide_rows(rows); return T3_OK; }
 
 extern "C" int t3k_gemm(const void* x, const void* w, int32_t M, int32_t K, int32_t N, float* out, int32_t mt, int32_t nw) {
-    if (!x || !w || !out || M <= 0 || N <= 0 || (nw != 4 && nw != 16) || K % (32 * nw)) return T3_E_INVALID;
+    if (!x || !w || !out || M <= 0 || N <= 0 || (nw != 4 && nw != 16) || !(nw == 4 ? K == D : ((K == D || K == F) && N % 16 == 0))) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
     const int Npad = (N + 15) / 16 * 16;
     std::vector<uint16_t> packed((size_t)Npad * K);
@@ -150,14 +150,10 @@ extern "C" int t3k_rope_attention(const void* qkv, const int32_t* row_stream, co
  *     reads the K / V that launch s - 1 wrote through the fused path.
  * out [steps][rows][1024]; kv_new (nullable) [steps][rows][2][1024]: K (rotated) and V of the positions the launches wrote, read
  * back from the pool. */
-// new_rows: [steps][rows][3072] pre-RoPE qkv rows (wqkv_packed == nullptr: the fused attention kernel), or [steps][rows][1024] residual rows
-// with wqkv_packed = the packed, norm-folded qkv matrix on the host (the one-launch projection + attention kernel of small steps)
-static int decode_attention_impl(const void* ctx_qkv, int32_t n_content, int32_t content_rows, const void* new_rows, const uint16_t* wqkv_packed, const int32_t* ctx,
-                                 int32_t rows, int32_t steps, int32_t max_pos, int32_t waves, void* out, void* kv_new) {
-    const void* new_qkv = new_rows;
+extern "C" int t3k_decode_attention(const void* ctx_qkv, int32_t n_content, int32_t content_rows, const void* new_qkv, const int32_t* ctx,
+                                    int32_t rows, int32_t steps, int32_t max_pos, int32_t waves, void* out, void* kv_new) {
     if (!ctx_qkv || !new_qkv || !ctx || !out || rows <= 0 || steps <= 0 || n_content <= 0 || content_rows <= 0 || max_pos <= 0 ||
         (waves != 0 && waves != 4 && waves != 8)) return T3_E_INVALID;
-    if (wqkv_packed && !qkv_in_attention_fits(rows, (max_pos + CHUNK - 1) / CHUNK)) return T3_E_INVALID;
     for (int r = 0; r < rows; ++r)
         if (ctx[r] < 1 || ctx[r] - 1 > content_rows || ctx[r] - 1 + steps > max_pos) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
@@ -173,13 +169,7 @@ static int decode_attention_impl(const void* ctx_qkv, int32_t n_content, int32_t
     rope_tables(max_pos, c.data(), s.data());
     const int stride = row_stride_words(max_blocks);
     DevBuf dctx, dnew, dc, ds, dq, dkv, dout, dkvn, drec_fill, drec;
-    DevBuf dw, dqkv_out, dsync;
-    const int sync_words = (qkv_in_attention_sync_words(rows) + 15) & ~15;
-    if (wqkv_packed) {
-        K_TRY(dw.from(wqkv_packed, (size_t)QKV * D * 2));
-        K_TRY(dqkv_out.alloc((size_t)rows * QKV * 2, true)); K_TRY(dsync.alloc((size_t)sync_words * 4, true));
-    }
-    K_TRY(dctx.from(ctx_qkv, (size_t)n_content * content_rows * QKV * 2)); K_TRY(dnew.from(new_qkv, (size_t)steps * rows * (wqkv_packed ? D : QKV) * 2));
+    K_TRY(dctx.from(ctx_qkv, (size_t)n_content * content_rows * QKV * 2)); K_TRY(dnew.from(new_qkv, (size_t)steps * rows * QKV * 2));
     K_TRY(dc.from(c.data(), c.size() * 4)); K_TRY(ds.from(s.data(), s.size() * 4));
     K_TRY(dq.alloc((size_t)content_rows * D * 2));                     // rotated q of the fill rows: not used
     K_TRY(dkv.alloc((size_t)nb * KV_BLOCK_ELEMS * 2, true)); K_TRY(dout.alloc((size_t)steps * rows * D * 2, true));
@@ -215,37 +205,13 @@ static int decode_attention_impl(const void* ctx_qkv, int32_t n_content, int32_t
         AttnArgs aa{nullptr, dkv.as<uint16_t>(), drec.as<int>(), stride, dout.as<uint16_t>() + (size_t)st * rows * D, rows, (max_pos + CHUNK - 1) / CHUNK,
                     dnew.as<uint16_t>() + (size_t)st * rows * QKV, dkv.as<uint16_t>(), dc.as<float>(), ds.as<float>()};
         aa.force_waves = waves;
-        if (wqkv_packed) {
-            K_TRY(hipMemset(dsync.p, 0, (size_t)sync_words * 4));      // every polled word is zero at launch (the engine's embed kernel does this per step)
-            aa.qkv = dqkv_out.as<uint16_t>();
-            K_TRY(launch_qkv_in_attention(dnew.as<uint16_t>() + (size_t)st * rows * D, dw.as<uint4>(), dqkv_out.as<uint16_t>(), dsync.as<unsigned>(), aa, nullptr));
-            K_TRY(hipDeviceSynchronize());
-            unsigned gave_up = 0;
-            K_TRY(hipMemcpy(&gave_up, dsync.as<unsigned>() + 1, 4, hipMemcpyDeviceToHost));
-            if (gave_up) return T3_E_DEVICE;                            // a workgroup stopped waiting for a projection unit
-        } else K_TRY(launch_attention(aa, nullptr));
+        K_TRY(launch_attention(aa, nullptr));
         K_TRY(launch_kv_gather(dkv.as<uint16_t>(), drec.as<int>(), stride, rows, dkvn.as<uint16_t>() + (size_t)st * rows * 2 * D, nullptr));
         K_TRY(hipDeviceSynchronize());
     }
     K_TRY(hipMemcpy(out, dout.p, (size_t)steps * rows * D * 2, hipMemcpyDeviceToHost));
     if (kv_new) K_TRY(hipMemcpy(kv_new, dkvn.p, (size_t)steps * rows * 2 * D * 2, hipMemcpyDeviceToHost));
     return T3_OK;
-}
-
-extern "C" int t3k_decode_attention(const void* ctx_qkv, int32_t n_content, int32_t content_rows, const void* new_qkv, const int32_t* ctx,
-                                    int32_t rows, int32_t steps, int32_t max_pos, int32_t waves, void* out, void* kv_new) {
-    return decode_attention_impl(ctx_qkv, n_content, content_rows, new_qkv, nullptr, ctx, rows, steps, max_pos, waves, out, kv_new);
-}
-
-/* The qkv projection inside the fused decode attention launch (qkv_in_attention_kernel): as t3k_decode_attention, but launch s takes the
- * residual rows h[s][r] ([steps][rows][1024] bf16) and projects them itself: q | k | v = bf16(rstd * GEMM(h, bf16(Wqkv * ln_w))). */
-extern "C" int t3k_qkv_decode_attention(const void* ctx_qkv, int32_t n_content, int32_t content_rows, const void* h_rows, const void* ln_w, const void* wqkv,
-                                        const int32_t* ctx, int32_t rows, int32_t steps, int32_t max_pos, void* out, void* kv_new) {
-    if (!h_rows || !ln_w || !wqkv) return T3_E_INVALID;
-    std::vector<uint16_t> folded((size_t)QKV * D), packed((size_t)QKV * D);
-    fold_norm_weight((const uint16_t*)wqkv, QKV, D, (const uint16_t*)ln_w, folded.data());      // what the engine does once at load time
-    pack_weight(folded.data(), QKV, D, QKV, packed.data());
-    return decode_attention_impl(ctx_qkv, n_content, content_rows, h_rows, packed.data(), ctx, rows, steps, max_pos, 0, out, kv_new);
 }
 
 extern "C" int t3k_sample(const void* logits2, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg, uint32_t step,

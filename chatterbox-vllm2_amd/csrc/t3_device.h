@@ -1,10 +1,30 @@
-// Device-side helpers shared by the kernel translation units (t3_kernels.hip, chain_kernel.hip): bf16 conversions at the
+// Device-side helpers shared by the kernel translation units (t3_gemm.hip, t3_attention.hip, t3_kernels.hip, tools/chain_kernel.hip): bf16 conversions at the
 // contract's rounding points, the contract exp, SwiGLU, MFMA fragment types and streamed loads.  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace t3 {
+
+// Profile mode (engine.cpp: Prof): the NEXT single-kernel launch of this thread carries these two events as its start / stop events
+// (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps, what rocprofv3 reports), instead of being bracketed by two
+// hipEventRecord barrier packets, which add ~2-3 us of command-processor time to a 5-30 us kernel.
+inline thread_local hipEvent_t g_arm_start = nullptr, g_arm_stop = nullptr;
+template <typename F, typename... Args>
+static inline void launch_k(F kernel, const dim3& grid, const dim3& block, size_t lds, hipStream_t s, Args... args) {
+    if (g_arm_start) {
+        hipEvent_t a = g_arm_start, b = g_arm_stop;
+        g_arm_start = nullptr; g_arm_stop = nullptr;
+        hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, s, a, b, 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+    }
+}
+// hipFuncSetAttribute applies to the CURRENT device: every "already raised" flag of a launcher is kept per device, so a process that
+// drives engines on several GPUs (LLM(device_id=...)) raises the limits on each of them
+constexpr int MAX_DEVICES = 64;
+static inline int cur_device() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < MAX_DEVICES ? d : 0; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -1,0 +1,961 @@
+// GEMM kernels of the T3 decode engine for gfx950 (MI355X, CDNA4): the decode schedules (gemm2_kernel, gemm2_loop_kernel), the
+// prefill schedule (pgemm_kernel) and their launchers.  wave = 64 lanes.
+//
+// Every floating-point rounding point and summation order in this file is part of the numerics contract written down in
+// DESIGN.md ("Numerics contract").  Compile with -ffp-contract=off: every fused multiply-add is an explicit __builtin_fmaf.
+// Reference semantics: the Llama block of src/chatterbox_vllm/models/t3/t3.py:696-713 -> vllm LlamaModel
+// (hyper-parameters t3-model/config.json:1-33), logits t3.py:650-673.
+#include "t3_kernels.h"
+#include "t3_device.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <utility>
+
+namespace t3 {
+// ------------------------------------------------------------------------------------------------
+// Skinny GEMM  y[m][n] = sum_k x[m][k] * W[n][k]   (x, W bf16, fp32 accumulation on the matrix cores)
+//
+// Contract order (DESIGN.md "GEMM"): K is cut into NW contiguous segments (one per wave of the workgroup,
+// NW = 4 or 16); a wave folds its segment with a chain of v_mfma_f32_16x16x32_bf16 in ascending k (each
+// instruction folds 4 blocks of 8 consecutive k into the fp32 accumulator; its exact arithmetic was
+// identified on-device and is restated in the checker); four consecutive segments give a group sum
+// G = ((s0 + s1) + s2) + s3 in fp32; with 16 segments (o_proj, down_proj) the result is ((G0 + G1) + G2) + G3.
+//
+// NORM form (qkv, gate/up, speech head; K = 1024, NW = 4): the RMSNorm that precedes the projection is folded in -- its
+// weight into the packed matrix at load time (W' = bf16(W * w_ln), fold_norm_weight()), its row statistic sum(h^2) onto the
+// matrix cores (a wave multiplies its A fragments with themselves and reads the diagonal: the same MFMA chain per segment as
+// the GEMM itself), and rstd = 1/sqrt(ss/1024 + eps) into the epilogue.  The activations reach the MFMAs untouched.
+// Statistic order: per wave (segment) one chain from +0 in ascending k; the four segment sums fold ((S0 + S1) + S2) + S3.
+//
+// One workgroup = NW waves = NT n-tiles of 16 columns x MT m-tiles of 16 rows.  Weights are packed so that a
+// wave's weight load is one contiguous 1 KiB (pack_weight).  (The round-1 schedule -- both operands through a symmetric
+// register ring, fragment-shaped activation loads -- is kept for the record in tools/legacy/gemm_kernel_r1.hip.)
+// ------------------------------------------------------------------------------------------------
+#ifdef T3_GEMM_CLK      // diagnostic build only (tools/gemm_clk.hip): per-workgroup phase stamps, 100 MHz ticks
+// gemm2_kernel (the decode schedule): class 0 qkv / head, 1 gate/up, 2 o, 3 down; stamps: 0 entry, 1 A rows landed and staged
+// in LDS, 2 first weight k-block landed, 3 last MFMA issued, 4 partials exchanged (barrier passed), 5 outputs stored
+__device__ unsigned long long g_gemm2_clk[4][2048][6];
+extern "C" int t3_debug_gemm2_clk(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm2_clk), sizeof(g_gemm2_clk)); }
+#define T3_G2STAMP(i) do { if (threadIdx.x == 0) g_gemm2_clk[NORM ? (EPI == EPI_SILU ? 1 : 0) : (KBS == 2 ? 2 : 3)][(blockIdx.y * gridDim.x + blockIdx.x) & 2047][i] = wall_clock64(); } while (0)
+#else
+#define T3_G2STAMP(i)
+#endif
+// ------------------------------------------------------------------------------------------------
+// gemm2_kernel: the decode schedule of the NORM forms (NW = 4, K = 1024, MT <= 2) and of the 16-segment forms at one
+// m-tile per workgroup (o_proj / down_proj).  What matters in how the bytes move:
+//   * A operand: a wave reads its K slice of its 16 rows as FULL row segments (KBS * 64 contiguous bytes per row, whole
+//     128-byte lines) into a wave-private, XOR-swizzled LDS image and takes its MFMA fragments from there with ds_read_b128.
+//     Fragment-shaped global loads (16 rows x 64 B per instruction, half lines: the round-1 kernel) cost the texture path twice
+//     the cycles per byte: at 64 rows the activations were 3.8 us of a 29 us layer (tools/chain_proto.hip, -DT3_GEMM_XDUMMY).
+//   * every weight tile of the wave's K slice is requested up front (KBS * NT KiB in flight per wave, no refill logic), behind
+//     the A loads, so the A image is in LDS while the weights are still in flight.
+// The partial sums of the cross-wave fold reuse the wave's own A image (dead after the K loop), so LDS = the A images only.
+// NORM: rstd from the MFMA diagonal (see the header of this section); the weights carry the norm weight already.
+// ------------------------------------------------------------------------------------------------
+// Loads whose ISSUE ORDER matters (gemm2_kernel): inline asm, so hipcc neither reorders nor counts them.  Every wait below is
+// hand-counted (vmcnt retires in issue order), and names the registers it releases as read-write operands, so no consumer can be
+// scheduled above it (cdna_hip_programming.md 5.7, form (ii)).
+typedef unsigned int uint4_v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gload16(uint4_v& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void gload16_nt(uint4_v& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(d) : "v"(p) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <typename Fn, int... Is>
+__device__ __forceinline__ void static_for(Fn&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+__device__ __forceinline__ void landed(uint4_v& d) { asm volatile("" : "+v"(d)); }          // d is defined from here on
+__device__ __forceinline__ bf16x8 as_frag4(const uint4_v& v) { union { uint4_v u; bf16x8 f; } c; c.u = v; return c.f; }
+template <int KBS>
+__device__ __forceinline__ unsigned a_img_off(int row, int ch) {     // byte offset of 16-byte chunk ch of row `row` in a wave's A image
+    if constexpr (KBS >= 4) return (unsigned)(row * (KBS * 64) + ((ch ^ (row & 15)) << 4));        // >= 256-byte rows: one row per bank row
+    else return (unsigned)(row * (KBS * 64) + ((ch ^ ((row >> 1) & (KBS * 4 - 1))) << 4));          // 128-byte rows: two rows per bank row
+}
+
+// PrefetchArgs (t3_kernels.h): this workgroup's share of a later launch's weight lines.  cls = this workgroup's XCD (its linear id % 8),
+// idx / n = its index among / the number of (workgroup, wave) slots of that XCD that take part; dump = LDS byte address (wave-uniform) of
+// 256 bytes nobody reads.  The loads count in vmcnt like any other and retire in issue order: issue them BEHIND every load the wave
+// still waits for; nothing waits for them (s_endpgm does).
+__device__ __forceinline__ void prefetch_next_weights(const PrefetchArgs& pf, int cls, int idx, int n, int lane, unsigned dump) {
+    if (!pf.base) return;
+    const int groups = pf.n_tiles / pf.group, groups_cls = groups >> 3;      // callers: groups is a multiple of 8
+    const int glines = pf.max_lines > 0 && pf.max_lines < pf.group * pf.tile_lines ? pf.max_lines : pf.group * pf.tile_lines;
+    const int total = groups_cls * glines, cnt = (total + n - 1) / n;
+    for (int j = 0; j * 64 < cnt && j < 32; ++j) {
+        const int k = lane + 64 * j, l = idx * cnt + k;
+        if (k < cnt && l < total) {
+            const int g = cls + 8 * (l / glines), rem = l % glines;
+            const unsigned char* p = pf.base + ((size_t)g * pf.group * pf.tile_lines + rem) * 128;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(p), "s"(dump) : "memory");
+        }
+    }
+}
+
+// EW: extra waves that sleep at the barrier and then share the epilogue.  The fold + epilogue of the 4-wave forms is a dependent chain of
+// ~300 vector instructions per thread (eight LDS reads, rstd, four SiLU-mul outputs with correctly rounded divisions) issued by ONE wave per
+// SIMD: 1.32 us of gate/up's 6.1 us, 0.52 of qkv's 3.6 (stamps, profiles/r03_gemm_clk_m64.txt).  With four more waves every thread
+// finishes two columns instead of four and two waves share each SIMD's issue slots.
+#ifndef T3_GEMM2_EW
+#define T3_GEMM2_EW 4
+#endif
+template <int NW> constexpr int gemm2_ew() { return NW == 4 ? T3_GEMM2_EW : 0; }
+// AV: how many of the KBS A-row instructions per m-tile a wave issues.  An instruction covers RPI consecutive rows, and the texture
+// path charges a padded row like a real one: a decode step of 1-4 utterances has 2-8 rows in its 16-row tile, and at 2 rows the
+// padding was as many bytes through the CU's load path as the workgroup's weights.  The launcher picks the smallest AV whose rows
+// cover M (one m-tile, one m-group); the image rows beyond are zero (row m of the accumulator depends on image row m alone, and
+// rows >= M are never stored).  A template parameter, not a branch: conditional asm loads make hipcc build the register tuples by copies.
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM, int AV = KBS>
+__global__ __launch_bounds__((NW + gemm2_ew<NW>()) * 64) void gemm2_kernel(GemmArgs a) {
+    T3_G2STAMP(0);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];      // [NW waves][MT][16 rows][KBS * 64 B] | NORM: float [NW][MT*16]
+    static_assert(NT <= KBS && (KBS == 8 || KBS == 2) && (NW == 4 || NW == 16) && AV >= 1 && AV <= KBS && (AV == KBS || MT == 1), "gemm2 shapes");
+    constexpr int LPR = KBS * 4, RPI = 64 / LPR;                // lanes (= 16-byte chunks) per row slice, rows per wave instruction
+    constexpr int ABYTES = MT * KBS * 1024, TILES = MT * NT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int KB = a.K >> 5, kb0 = wave * KBS;
+    unsigned char* aimg = lds2 + (size_t)wave * ABYTES;
+    float* rowsum = reinterpret_cast<float*>(lds2 + (size_t)NW * ABYTES);
+
+    // EPI_RESID (16-wave form, one output per thread): the residual operand is requested first (a compiler-counted load: it must be older than the asm loads)
+    uint16_t hres = 0;
+    if constexpr (EPI == EPI_RESID) {
+        const int r = (tid >> 6) & 3, l2 = tid & 63;
+        const int m = blockIdx.y * 16 + 4 * (l2 >> 4) + r, n = blockIdx.x * 16 + (l2 & 15);
+        if (tid < 256 && m < a.M && n < a.N) hres = reinterpret_cast<const uint16_t*>(a.out)[(size_t)m * a.ldo + n];
+    }
+    constexpr int EW = gemm2_ew<NW>();
+    if (EW == 0 || wave < NW) {          // the compute waves; the EW epilogue waves go straight to the barrier
+    // ---- A: full row segments of this wave's K slice
+    uint4_v ar[MT][KBS];
+    const int rsub = lane / LPR, ch = lane % LPR;
+    int mrow[MT][KBS];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < KBS; ++t) {
+            const int m = (blockIdx.y * MT + i) * 16 + t * RPI + rsub;
+            mrow[i][t] = m < a.M ? m : a.M - 1;        // padded rows re-read the last row; their outputs are dropped
+        }
+    if (a.row_index) {                                 // ONE branch around all the gather loads (a select per element would serialise them)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < KBS; ++t) mrow[i][t] = a.row_index[mrow[i][t]];
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < KBS; ++t) {
+            if constexpr (AV < KBS) { if (t >= AV) { ar[i][t] = (uint4_v){0u, 0u, 0u, 0u}; continue; } }
+            gload16(ar[i][t], a.X + (size_t)mrow[i][t] * a.K + kb0 * 32 + ch * 8);
+        }
+    // ---- W: every tile of this wave's K slice, behind the A loads and before the first wait (left to itself, hipcc sinks these
+    // loads below the staging block to save registers, i.e. behind a full L2 round trip)
+    uint4_v wr[KBS][NT];
+#pragma unroll
+    for (int kb = 0; kb < KBS; ++kb)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gload16_nt(wr[kb][t], a.Wp + ((size_t)(blockIdx.x * NT + t) * KB + kb0 + kb) * 64 + lane);
+    // ---- stage A (wave-private: a wave's DS operations execute in order, no barrier).  The KBS * NT weight loads are younger.
+    wait_vmcnt<KBS * NT>();
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < AV; ++t) landed(ar[i][t]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < KBS; ++t)
+            *reinterpret_cast<uint4_v*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(t * RPI + rsub, ch)) = ar[i][t];
+    asm volatile("" ::: "memory");
+    T3_G2STAMP(1);
+    f32x4 acc[MT][NT], ss[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        ss[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    static_for([&](auto kbc) {
+        constexpr int kb = decltype(kbc)::value;
+        uint4 af[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(c, 4 * kb + q));
+        wait_vmcnt<(KBS - 1 - kb) * NT>();            // this k-block's NT weight tiles have landed ((KBS - 1 - kb) * NT younger loads may still fly)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) landed(wr[kb][t]);
+        if constexpr (kb == 0) T3_G2STAMP(2);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if constexpr (NORM) ss[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(af[i]), ss[i], 0, 0, 0);   // diagonal = sum of squares
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][t]), acc[i][t], 0, 0, 0);
+        }
+    }, std::make_integer_sequence<int, KBS>{});
+    T3_G2STAMP(3);
+    // ---- partials over the wave's own (now dead) A image: [tile][r][lane]
+    asm volatile("" ::: "memory");
+    float* redw = reinterpret_cast<float*>(aimg);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) redw[((i * NT + t) * 4 + r) * 64 + lane] = acc[i][t][r];
+    if constexpr (NORM) {
+        // D[row = 4 q + r][col = c]: the diagonal element of row c sits in lane group q = c / 4, register c % 4
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int r = c & 3;
+            const float d = r == 0 ? ss[i][0] : r == 1 ? ss[i][1] : r == 2 ? ss[i][2] : ss[i][3];
+            if ((c >> 2) == q) rowsum[wave * (MT * 16) + i * 16 + c] = d;
+        }
+    }
+    }                                     // compute waves
+    __syncthreads();
+    T3_G2STAMP(4);
+    if constexpr (EW > 0) {
+        // PrefetchArgs: every operand of the workgroup has landed and the memory system idles until the stores: the epilogue waves ask for
+        // their share of the next launch's weights before they start folding (dump corner: the 256 bytes behind everything else in LDS)
+        if (wave >= NW && ((gridDim.x * gridDim.y) & 7) == 0) {
+            const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+            const unsigned dump = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(lds2 + (size_t)NW * ABYTES + (NORM ? NW * MT * 16 * sizeof(float) : 0));
+            prefetch_next_weights(a.pf, lin & 7, (lin >> 3) * EW + (wave - NW), ((gridDim.x * gridDim.y) >> 3) * EW, lane, dump);
+        }
+    }
+    auto part = [&](int w) { return reinterpret_cast<const float*>(lds2 + (size_t)w * ABYTES); };
+
+    if constexpr (NW == 4) {
+        // CW outputs (one row, CW columns) per thread and step: four (16-byte LDS reads, 8-byte stores) with the compute waves alone,
+        // two with the epilogue waves
+        constexpr int CW = EW ? 2 : 4, PPT = 16 / CW;                       // pieces per 16-column tile row
+        constexpr int NTO = (EPI == EPI_SILU) ? NT / 2 : NT, PIECES = MT * NTO * 16 * PPT, TH = (NW + EW) * 64, PIT = (PIECES + TH - 1) / TH;
+#pragma unroll
+        for (int k = 0; k < PIT; ++k) {
+            const int p = tid + k * TH;
+            if (p >= PIECES) continue;
+            const int ito = p / (16 * PPT), r16 = (p / PPT) & 15, qq = p % PPT;
+            const int i = ito / NTO, to = ito % NTO;
+            const int m = (blockIdx.y * MT + i) * 16 + r16;
+            if (m >= a.M) continue;
+            const int g = r16 >> 2, r = r16 & 3;
+            float v[EPI == EPI_SILU ? 2 : 1][CW];
+#pragma unroll
+            for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u) {
+                const int it = i * NT + (EPI == EPI_SILU ? 2 * to + u : to);
+                const int o = (it * 4 + r) * 64 + 16 * g + CW * qq;
+                if constexpr (CW == 4) {
+                    const float4 s0 = *reinterpret_cast<const float4*>(part(0) + o), s1 = *reinterpret_cast<const float4*>(part(1) + o),
+                                 s2 = *reinterpret_cast<const float4*>(part(2) + o), s3 = *reinterpret_cast<const float4*>(part(3) + o);
+                    v[u][0] = ((s0.x + s1.x) + s2.x) + s3.x; v[u][1] = ((s0.y + s1.y) + s2.y) + s3.y;
+                    v[u][2] = ((s0.z + s1.z) + s2.z) + s3.z; v[u][3] = ((s0.w + s1.w) + s2.w) + s3.w;
+                } else {
+                    const float2 s0 = *reinterpret_cast<const float2*>(part(0) + o), s1 = *reinterpret_cast<const float2*>(part(1) + o),
+                                 s2 = *reinterpret_cast<const float2*>(part(2) + o), s3 = *reinterpret_cast<const float2*>(part(3) + o);
+                    v[u][0] = ((s0.x + s1.x) + s2.x) + s3.x; v[u][1] = ((s0.y + s1.y) + s2.y) + s3.y;
+                }
+            }
+            if constexpr (NORM) {
+                const int rl = i * 16 + r16;
+                const float ssum = ((rowsum[rl] + rowsum[MT * 16 + rl]) + rowsum[2 * MT * 16 + rl]) + rowsum[3 * MT * 16 + rl];
+                const float rstd = 1.0f / sqrtf(ssum * (1.0f / 1024.0f) + 1e-5f);
+#pragma unroll
+                for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u)
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) v[u][e] = v[u][e] * rstd;
+            }
+            const int n = (blockIdx.x * NTO + to) * 16 + CW * qq;
+            if (n >= a.N) continue;
+            if constexpr (EPI == EPI_F32) {
+                float* op = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n;
+#pragma unroll
+                for (int e = 0; e < CW; ++e) if (n + e < a.N) op[e] = v[0][e];
+            } else {
+                uint32_t ob[CW];
+#pragma unroll
+                for (int e = 0; e < CW; ++e) ob[e] = (EPI == EPI_SILU) ? silu_mul_bf(f2bf(v[0][e]), f2bf(v[EPI == EPI_SILU ? 1 : 0][e])) : f2bf(v[0][e]);
+                uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
+                if (n + CW - 1 < a.N || a.ldo >= ((a.N + CW - 1) & ~(CW - 1))) {
+                    if constexpr (CW == 4) *reinterpret_cast<uint2*>(op) = make_uint2(ob[0] | (ob[1] << 16), ob[2] | (ob[3] << 16));
+                    else *reinterpret_cast<uint32_t*>(op) = ob[0] | (ob[1] << 16);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) if (n + e < a.N) op[e] = (uint16_t)ob[e];
+                }
+            }
+        }
+    } else {
+        // 16 segments: one output per thread (256 of the 1024 threads), ((G0 + G1) + G2) + G3 with G = ((s0 + s1) + s2) + s3
+        if (tid < 256) {
+            const int r = (tid >> 6) & 3, l2 = tid & 63;
+            const int m = blockIdx.y * 16 + 4 * (l2 >> 4) + r, n = blockIdx.x * 16 + (l2 & 15);
+            if (m < a.M && n < a.N) {
+                const int o = r * 64 + l2;
+                float tot = 0.0f;
+#pragma unroll
+                for (int gsum = 0; gsum < 4; ++gsum) {
+                    float s4 = part(4 * gsum)[o];
+                    s4 = s4 + part(4 * gsum + 1)[o]; s4 = s4 + part(4 * gsum + 2)[o]; s4 = s4 + part(4 * gsum + 3)[o];
+                    tot = gsum == 0 ? s4 : tot + s4;
+                }
+                if constexpr (EPI == EPI_F32) reinterpret_cast<float*>(a.out)[(size_t)m * a.ldo + n] = tot;
+                else if constexpr (EPI == EPI_BF16) reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)f2bf(tot);
+                else reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)f2bf(bf2f(hres) + rbf(tot));     // EPI_RESID: h = bf16(h + bf16(y))
+            }
+        }
+    }
+    T3_G2STAMP(5);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm2_loop_kernel: gate/up (4 waves, two gate/up pairs per workgroup), o and down (16 waves) from 65-81 rows on (decode steps of
+// 41+ utterances, C4; thresholds and measurements in launch_gemm).  gemm2_kernel launches one
+// workgroup per (n-group, m-group): at 256 rows that is 1024 single-occupancy workgroups in four rounds, each of which streams its
+// weight tiles again (268 MB of L2 -> CU traffic per layer) and pays a cold start.  Here a workgroup OWNS an n-group: its weight
+// tiles are loaded once and stay in registers, and it walks the m-groups, the next group's activation rows in flight (asm loads)
+// while the current group runs on the matrix cores.  Same numbers: every (row, column) is computed exactly as in gemm2_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
+__global__ __launch_bounds__(NW * 64) void gemm2_loop_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];      // [NW waves][MT][16 rows][KBS * 64 B] | NORM: float [NW][MT*16]
+    static_assert(NT <= KBS && (KBS == 8 || KBS == 2) && (NW == 4 || NW == 16) && (NW == 4 || (MT == 1 && NT <= 2)), "gemm2_loop shapes");
+    constexpr int LPR = KBS * 4, RPI = 64 / LPR, ABYTES = MT * KBS * 1024, TILES = MT * NT;
+    constexpr int NTO = (EPI == EPI_SILU) ? NT / 2 : NT, PIECES = MT * NTO * 64, PIT = (PIECES + 255) / 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int KB = a.K >> 5, kb0 = wave * KBS;
+    unsigned char* aimg = lds2 + (size_t)wave * ABYTES;
+    float* rowsum = reinterpret_cast<float*>(lds2 + (size_t)NW * ABYTES);
+    const int rsub = lane / LPR, ch = lane % LPR;
+    const int mgroups = ((a.M + 15) / 16 + MT - 1) / MT;
+    uint4_v ar[MT][KBS], wr[KBS][NT];
+    auto issue_a = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < KBS; ++t) {
+                int m = (g * MT + i) * 16 + t * RPI + rsub;
+                m = m < a.M ? m : a.M - 1;
+                gload16(ar[i][t], a.X + (size_t)m * a.K + kb0 * 32 + ch * 8);
+            }
+    };
+    auto stage_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < KBS; ++t) landed(ar[i][t]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < KBS; ++t)
+                *reinterpret_cast<uint4_v*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(t * RPI + rsub, ch)) = ar[i][t];
+        asm volatile("" ::: "memory");
+    };
+    auto group = [&](int g, auto first_c, uint16_t hres) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        f32x4 acc[MT][NT], ss[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            ss[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        static_for([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            uint4 af[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(c, 4 * kb + q));
+            if constexpr (FIRST) {     // the weights land during the first group: younger = the later weight tiles + the next group's rows
+                wait_vmcnt<(KBS - 1 - kb) * NT + MT * KBS>();
+#pragma unroll
+                for (int t = 0; t < NT; ++t) landed(wr[kb][t]);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (NORM) ss[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(af[i]), ss[i], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][t]), acc[i][t], 0, 0, 0);
+            }
+        }, std::make_integer_sequence<int, KBS>{});
+        asm volatile("" ::: "memory");
+        float* redw = reinterpret_cast<float*>(aimg);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) redw[((i * NT + t) * 4 + r) * 64 + lane] = acc[i][t][r];
+        if constexpr (NORM) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r = c & 3;
+                const float d = r == 0 ? ss[i][0] : r == 1 ? ss[i][1] : r == 2 ? ss[i][2] : ss[i][3];
+                if ((c >> 2) == q) rowsum[wave * (MT * 16) + i * 16 + c] = d;
+            }
+        }
+        __syncthreads();
+        auto part = [&](int w) { return reinterpret_cast<const float*>(lds2 + (size_t)w * ABYTES); };
+        if constexpr (NW == 16) {
+            // 16 segments: one output per thread (256 NT of the 1024 threads), ((G0 + G1) + G2) + G3 with G = ((s0 + s1) + s2) + s3
+            if (tid < 256 * NT) {
+                const int tl = tid >> 8, r = (tid >> 6) & 3, l2 = tid & 63;
+                const int m = g * 16 + 4 * (l2 >> 4) + r, n = (blockIdx.x * NT + tl) * 16 + (l2 & 15);
+                if (m < a.M && n < a.N) {
+                    const int o = (tl * 4 + r) * 64 + l2;
+                    float tot = 0.0f;
+#pragma unroll
+                    for (int gsum = 0; gsum < 4; ++gsum) {
+                        float s4 = part(4 * gsum)[o];
+                        s4 = s4 + part(4 * gsum + 1)[o]; s4 = s4 + part(4 * gsum + 2)[o]; s4 = s4 + part(4 * gsum + 3)[o];
+                        tot = gsum == 0 ? s4 : tot + s4;
+                    }
+                    if constexpr (EPI == EPI_F32) reinterpret_cast<float*>(a.out)[(size_t)m * a.ldo + n] = tot;
+                    else reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)f2bf(bf2f(hres) + rbf(tot));     // EPI_RESID
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < PIT; ++k) {
+            const int p = tid + k * 256;
+            if (p >= PIECES) continue;
+            const int ito = p >> 6, r16 = (p >> 2) & 15, qq = p & 3;
+            const int i = ito / NTO, to = ito % NTO;
+            const int m = (g * MT + i) * 16 + r16;
+            if (m >= a.M) continue;
+            const int gq = r16 >> 2, r = r16 & 3;
+            float v[EPI == EPI_SILU ? 2 : 1][4];
+#pragma unroll
+            for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u) {
+                const int it = i * NT + (EPI == EPI_SILU ? 2 * to + u : to);
+                const int o = (it * 4 + r) * 64 + 16 * gq + 4 * qq;
+                const float4 s0 = *reinterpret_cast<const float4*>(part(0) + o), s1 = *reinterpret_cast<const float4*>(part(1) + o),
+                             s2 = *reinterpret_cast<const float4*>(part(2) + o), s3 = *reinterpret_cast<const float4*>(part(3) + o);
+                v[u][0] = ((s0.x + s1.x) + s2.x) + s3.x; v[u][1] = ((s0.y + s1.y) + s2.y) + s3.y;
+                v[u][2] = ((s0.z + s1.z) + s2.z) + s3.z; v[u][3] = ((s0.w + s1.w) + s2.w) + s3.w;
+            }
+            if constexpr (NORM) {
+                const int rl = i * 16 + r16;
+                const float ssum = ((rowsum[rl] + rowsum[MT * 16 + rl]) + rowsum[2 * MT * 16 + rl]) + rowsum[3 * MT * 16 + rl];
+                const float rstd = 1.0f / sqrtf(ssum * (1.0f / 1024.0f) + 1e-5f);
+#pragma unroll
+                for (int u = 0; u < (EPI == EPI_SILU ? 2 : 1); ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[u][e] = v[u][e] * rstd;
+            }
+            const int n = (blockIdx.x * NTO + to) * 16 + 4 * qq;
+            if (n >= a.N) continue;
+            uint32_t ob[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ob[e] = (EPI == EPI_SILU) ? silu_mul_bf(f2bf(v[0][e]), f2bf(v[EPI == EPI_SILU ? 1 : 0][e])) : f2bf(v[0][e]);
+            uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
+            if (n + 3 < a.N || a.ldo >= ((a.N + 3) & ~3)) *reinterpret_cast<uint2*>(op) = make_uint2(ob[0] | (ob[1] << 16), ob[2] | (ob[3] << 16));
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n + e < a.N) op[e] = (uint16_t)ob[e];
+            }
+        }
+    };
+
+    // the m-groups are dealt round-robin over gridDim.y workgroups per n-group (two workgroups per CU overlap one's epilogue with
+    // the other's matrix work); the launcher guarantees every workgroup at least two groups
+    const int g0 = blockIdx.y, gs = gridDim.y;
+    // EPI_RESID: the residual operand of a group is a compiler-counted load: requested before the asm loads of the first group (it
+    // must be the oldest there: the hand-counted waits assume only asm loads behind them), at the start of every later one
+    auto load_res = [&](int g) -> uint16_t {
+        if constexpr (EPI == EPI_RESID) {
+            const int tl = tid >> 8, r = (tid >> 6) & 3, l2 = tid & 63;
+            const int m = g * 16 + 4 * (l2 >> 4) + r, n = (blockIdx.x * NT + tl) * 16 + (l2 & 15);
+            if (tid < 256 * NT && m < a.M && n < a.N) return reinterpret_cast<const uint16_t*>(a.out)[(size_t)m * a.ldo + n];
+        }
+        return 0;
+    };
+    uint16_t hres = load_res(g0);
+    issue_a(g0);
+#pragma unroll
+    for (int kb = 0; kb < KBS; ++kb)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gload16_nt(wr[kb][t], a.Wp + ((size_t)(blockIdx.x * NT + t) * KB + kb0 + kb) * 64 + lane);
+    wait_vmcnt<KBS * NT>();                        // the first group's rows are in (the weight tiles are younger)
+    stage_a();
+    issue_a(g0 + gs);
+    group(g0, std::true_type{}, hres);
+    for (int g = g0 + gs; g < mgroups; g += gs) {
+        __syncthreads();                           // every wave is done with the previous group's partials: the A images may be overwritten
+        wait_vmcnt<0>();                           // this group's rows (nothing younger is in flight)
+        stage_a();
+        hres = load_res(g);
+        if (g + gs < mgroups) issue_a(g + gs);
+        group(g, std::false_type{}, hres);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prefill-sized GEMM (M >= 256 rows): the same numbers as gemm2_kernel, another schedule.  A workgroup of four waves owns a
+// 128-row x 64-column tile (4 packed n-tiles); every K step of 32 is staged once through LDS (activations 128 x 64 B row
+// pieces; weights: 4 packed 1 KiB fragments, the NORM forms' carrying the norm weight) and feeds 32 MFMAs, so a weight byte is
+// re-read once per 128 rows instead of once per 32 and an activation byte once per 64 columns instead of once per workgroup.
+// Contract order per output: one MFMA chain per K segment FROM ZERO in ascending k; segments folded left to right in groups
+// of four (G = ((s0 + s1) + s2) + s3), groups folded left to right -- hence three accumulator sets (segment, group, total).
+// The row statistic of the NORM forms comes from row_rstd_kernel (the same MFMA chains as gemm2_kernel's own).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_rstd_kernel(const uint16_t* h, float* rstd, int rows) {
+    // one wave per 16 rows: per segment of 256 k the wave multiplies its A fragments with themselves (one MFMA chain from +0,
+    // ascending k) and keeps the diagonal; the four segment sums fold ((S0 + S1) + S2) + S3 -- gemm2_kernel's own statistic
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int mt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (mt * 16 >= rows) return;
+    int m = mt * 16 + c; m = m < rows ? m : rows - 1;
+    const uint4* xp = reinterpret_cast<const uint4*>(h + (size_t)m * D + q * 8);
+    float tot = 0.0f;
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg) {
+        f32x4 ss = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const uint4 af = xp[(sg * 8 + kb) * 4];
+            ss = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag(af), ss, 0, 0, 0);
+        }
+        const int r = c & 3;
+        const float d = r == 0 ? ss[0] : r == 1 ? ss[1] : r == 2 ? ss[2] : ss[3];
+        tot = sg == 0 ? d : tot + d;
+    }
+    if ((c >> 2) == q && mt * 16 + c < rows) rstd[mt * 16 + c] = 1.0f / sqrtf(tot * (1.0f / 1024.0f) + 1e-5f);
+}
+
+__device__ __forceinline__ int pgemm_a_pos(int row, int q) { return (row << 2) + (((row >> 2) & 3) ^ ((4 - q) & 3)); }     // uint4 index in a stage's A image
+// one 1 KiB LDS-DMA piece: every lane's 16 bytes at gsrc land at lds_byte_addr (wave-uniform) + 16 * lane.  M0 carries the LDS
+// address and is written in the statement that uses it (cdna_hip_programming.md 5.7); hipcc does not count this load: every wait
+// for it below is hand-counted.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+// WC = packed n-tiles per wave: 2 (workgroup tile 128 x 64) or 4 (128 x 128: a fragment read from LDS feeds twice the MFMAs and a
+// weight / activation byte leaves L2 1.5 times less often; two accumulator sets of 64 registers, two workgroups per CU)
+template <int EPI, int NSEG, bool NORM, int WC>
+__global__ __launch_bounds__(256, WC == 4 ? 2 : (NSEG == 4 ? 4 : 3)) void pgemm_kernel(GemmArgs a, const float* rstd) {
+    // Operand ring in LDS, filled by LDS-DMA three K steps ahead of the MFMAs (no staging registers: the global-load latency of
+    // a step is covered by three steps of arithmetic instead of one).  Per stage: A image 128 rows x 64 B (swizzled, below) | 4
+    // weight fragments x 1 KiB.  The NORM forms' activations go in untouched (the norm weight lives in the packed matrix).
+#ifndef T3_PGEMM_NS
+#define T3_PGEMM_NS 3      // measured at 8192 rows: 3 stages (36 KiB, 4 workgroups per CU) 214 / 92 / 91 us (gate-up / o+down / qkv), 4 stages 235 / 91 / 99, 6 stages 296 / 96 / 121
+#endif
+#ifndef T3_PGEMM_NS_WIDE
+#define T3_PGEMM_NS_WIDE 3
+#endif
+    constexpr int NS = WC == 4 ? T3_PGEMM_NS_WIDE : T3_PGEMM_NS, AHEAD = NS - 1, NTW = 2 * WC, STAGE = 512 + NTW * 64;     // stages in the ring; n-tiles per workgroup; uint4 per stage
+    constexpr int PP = 2 + NTW / 4;                                              // DMA pieces per wave and stage
+    __shared__ __attribute__((aligned(16))) uint4 ring[NS * STAGE];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 1, wc = wave & 1;                                   // wave tile: rows 64 wr .., packed n-tiles 2 wc, 2 wc + 1
+    const int KB = a.K >> 5, kbs = KB / NSEG;
+    const int m0 = blockIdx.y * 128, nt0 = blockIdx.x * NTW;
+    // A image: 64-byte rows, so four rows share a 256-byte bank row and the 16 rows of a fragment read would hit 4 bank slots.
+    // Chunk q of row r sits at position ((r >> 2) & 3) ^ T[q], T = {0, 3, 2, 1} (an involution): the 16 lanes of each hardware
+    // lane group of ds_read_b128 then land on 16 different slots.  A DMA piece writes LDS linearly, so the permutation is applied
+    // to the SOURCE: the lane that fills position P = 4 row + p fetches chunk q = T[p ^ ((row >> 2) & 3)] of that row.
+    const uint16_t* xsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int P = t + 256 * j, row = P >> 2, q = (4 - ((P & 3) ^ ((row >> 2) & 3))) & 3;
+        int m = m0 + row; m = m < a.M ? m : a.M - 1;
+        xsrc[j] = a.X + (size_t)m * a.K + q * 8;
+    }
+    const uint4* wsrc = a.Wp + ((size_t)(nt0 + wave) * KB) * 64 + lane;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
+    auto issue = [&](int kb) {                                                 // PP 1 KiB pieces per wave and stage
+        const unsigned base = lds0 + (unsigned)(((kb % NS) * STAGE + wave * 64) * 16);
+        glds16(xsrc[0] + kb * 32, base);
+        glds16(xsrc[1] + kb * 32, base + 256 * 16);
+#pragma unroll
+        for (int j = 0; j < NTW / 4; ++j) glds16(wsrc + ((size_t)(4 * j) * KB + kb) * 64, base + (512 + 256 * j) * 16);
+    };
+    f32x4 sg[4][WC], gr[4][WC], tot[4][NSEG > 4 ? WC : 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int u = 0; u < WC; ++u) { sg[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f}; gr[i][u] = sg[i][u]; if (NSEG > 4) tot[i][u] = sg[i][u]; }
+
+#pragma unroll
+    for (int k0 = 0; k0 < AHEAD; ++k0) if (k0 < KB) issue(k0);
+    int kin = 0, seg = 0;
+    for (int kb = 0; kb < KB; ++kb) {
+        // stage kb has landed once every wave has seen its own three pieces of it: vmcnt retires in issue order, the pieces of the
+        // (up to two) younger stages may still fly.  lgkmcnt(0): this wave's fragment reads of the previous step are back, so the
+        // buffer that is refilled below is free.  A raw barrier: __syncthreads() would drain the DMA queue.
+        const int younger = KB - 1 - kb < AHEAD - 1 ? KB - 1 - kb : AHEAD - 1;      // stages behind this one that may still be in flight
+        switch (younger) {
+            case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PP) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PP) : "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * PP) : "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * PP) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(5 * PP) : "memory"); break;
+        }
+        __builtin_amdgcn_s_barrier();
+        const uint4* As = ring + (kb % NS) * STAGE;
+        const uint4* Bs = As + 512;
+        uint4 af[4], bf[WC];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = As[pgemm_a_pos(wr * 64 + i * 16 + (lane & 15), lane >> 4)];
+#pragma unroll
+        for (int u = 0; u < WC; ++u) bf[u] = Bs[(wc * WC + u) * 64 + lane];
+#ifndef T3_PGEMM_NODMA       // diagnostic builds only: which resource bounds the schedule
+        if (kb + AHEAD < KB) issue(kb + AHEAD);          // into the buffer of step kb - 1: every wave is past its reads (barrier above)
+#endif
+#ifdef T3_PGEMM_NOMFMA
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < WC; ++u) { sg[i][u][0] += __uint_as_float(af[i].x ^ bf[u].y); sg[i][u][1] += __uint_as_float(af[i].z ^ bf[u].w); }
+#else
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < WC; ++u)
+                sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(bf[u]), sg[i][u], 0, 0, 0);
+#endif
+        if (++kin == kbs) {                      // segment complete: fold it
+            const bool first_in_group = (seg & 3) == 0, last_in_group = (seg & 3) == 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int u = 0; u < WC; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gr[i][u][r] = first_in_group ? sg[i][u][r] : gr[i][u][r] + sg[i][u][r];
+                        if constexpr (NSEG > 4) { if (last_in_group) tot[i][u][r] = seg == 3 ? gr[i][u][r] : tot[i][u][r] + gr[i][u][r]; }
+                        sg[i][u][r] = 0.0f;
+                    }
+                }
+            kin = 0; ++seg;
+        }
+    }
+    // epilogue: D[row = 4 (lane >> 4) + r][col = lane & 15] of every 16 x 16 tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wr * 64 + i * 16 + 4 * (lane >> 4) + r;
+            if (m >= a.M) continue;
+            float v[WC];
+#pragma unroll
+            for (int u = 0; u < WC; ++u) { if constexpr (NSEG > 4) v[u] = tot[i][u][r]; else v[u] = gr[i][u][r]; }
+            if constexpr (NORM) {
+                const float rs = rstd[m];
+#pragma unroll
+                for (int u = 0; u < WC; ++u) v[u] = v[u] * rs;
+            }
+            if constexpr (EPI == EPI_SILU) {
+#pragma unroll
+                for (int u = 0; u < WC; u += 2) {                             // packed pair (gate, up) -> one output tile
+                    const int n = ((nt0 + wc * WC + u) >> 1) * 16 + (lane & 15);
+                    if (n < a.N) reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)silu_mul_bf(f2bf(v[u]), f2bf(v[u + 1]));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < WC; ++u) {
+                    const int n = (nt0 + wc * WC + u) * 16 + (lane & 15);
+                    if (n >= a.N) continue;
+                    if constexpr (EPI == EPI_F32) {
+                        reinterpret_cast<float*>(a.out)[(size_t)m * a.ldo + n] = v[u];
+                    } else {
+                        uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
+                        if constexpr (EPI == EPI_BF16) *op = (uint16_t)f2bf(v[u]);
+                        else *op = (uint16_t)f2bf(bf2f(*op) + rbf(v[u]));     // EPI_RESID: h = bf16(h + bf16(y))
+                    }
+                }
+            }
+        }
+    }
+}
+
+static int g_pgemm_min_rows = -1, g_pgemm_wide_rows = -1;
+static int g_gemm_small_m = 1;          // T3_GEMM_SMALL_M=0: the one-tile GEMMs issue every activation-row load (read again by every prepare_kernels call, i.e. per engine)
+void set_pgemm_min_rows(int rows) { g_pgemm_min_rows = rows; }
+void set_pgemm_wide_rows(int rows) { g_pgemm_wide_rows = rows; }
+
+// Large-M path of launch_gemm: returns hipErrorNotSupported when the shape is not one of the layer forms.
+static hipError_t launch_pgemm(const GemmArgs& a, int epi, hipStream_t s) {
+    const bool norm = a.norm != 0;
+    const int nseg = a.nw == 16 ? 16 : 4;
+    const int ntiles = (a.N + 15) / 16 * (epi == EPI_SILU ? 2 : 1);
+    if (a.row_index || ntiles % 4 || a.K % (32 * nseg) || (norm && (!a.rstd_scratch || a.K != D))) return hipErrorNotSupported;
+    // 128 x 128 tiles for the 4-segment forms from 2048 rows on only with T3_PGEMM_WC=4 (or the parity tests' hook): measured at
+    // 8 178 rows x 30 layers, a prefill step takes 18.35 ms with 128 x 64 tiles, 18.76 with 128 x 128 and a 3-stage ring, 19.07
+    // with a 4-stage ring -- the two workgroups per CU that fit hide less latency than the four of the narrow form
+    static int wc_env = -1;
+    if (wc_env < 0) { const char* e = getenv("T3_PGEMM_WC"); wc_env = e ? atoi(e) : 2; }
+    const int wide_rows = g_pgemm_wide_rows >= 0 ? g_pgemm_wide_rows : 2048;          // 0 = never
+    const bool wide = (wc_env == 4 || g_pgemm_wide_rows > 0) && nseg == 4 && ntiles % 8 == 0 && wide_rows > 0 && a.M >= wide_rows;
+    const dim3 grid(ntiles / (wide ? 8 : 4), (a.M + 127) / 128);
+#define T3_PG(E, SEG, NRM, RS) do { if (wide) hipLaunchKernelGGL((pgemm_kernel<E, SEG, NRM, 4>), grid, dim3(256), 0, s, a, (const float*)(RS)); \
+                                    else hipLaunchKernelGGL((pgemm_kernel<E, SEG, NRM, 2>), grid, dim3(256), 0, s, a, (const float*)(RS)); } while (0)
+    if (norm) {
+        hipLaunchKernelGGL(row_rstd_kernel, dim3((a.M + 63) / 64), dim3(256), 0, s, a.X, a.rstd_scratch, a.M);
+        if (epi == EPI_BF16) T3_PG(EPI_BF16, 4, true, a.rstd_scratch);
+        else if (epi == EPI_F32) T3_PG(EPI_F32, 4, true, a.rstd_scratch);
+        else if (epi == EPI_SILU) T3_PG(EPI_SILU, 4, true, a.rstd_scratch);
+        else return hipErrorNotSupported;
+    } else {
+        if (epi == EPI_RESID && nseg == 16) hipLaunchKernelGGL((pgemm_kernel<EPI_RESID, 16, false, 2>), grid, dim3(256), 0, s, a, (const float*)nullptr);
+        else if (epi == EPI_F32 && nseg == 16) hipLaunchKernelGGL((pgemm_kernel<EPI_F32, 16, false, 2>), grid, dim3(256), 0, s, a, (const float*)nullptr);
+        else if (epi == EPI_F32) T3_PG(EPI_F32, 4, false, nullptr);
+        else return hipErrorNotSupported;
+    }
+#undef T3_PG
+    return hipGetLastError();
+}
+
+int choose_mt(int M, int ntiles_x, int nw, bool norm) {
+    const int mtiles = (M + 15) / 16;
+    if (const char* e = getenv("T3_GEMM_MT")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) return v; }
+    // Largest row tile that (a) fits the register file / LDS (NORM form: 2 m-tiles; 16-wave form: 4) and (b) still launches
+    // enough workgroups: >= 512 for the 4-wave forms (measured: qkv is fastest at 768 workgroups, gate/up at 512),
+    // >= 256 for the 16-wave form.  Workgroups with the same blockIdx.x differ by a multiple of gridDim.x in linear id,
+    // and gridDim.x is a multiple of 8 for the layer GEMMs, so they land on the same XCD and share the weight tile in L2.
+    int cap = norm ? 2 : (nw == 16 ? 4 : 8);
+    if (norm) { if (const char* e = getenv("T3_GEMM_MT_NORM")) cap = atoi(e) >= 2 ? 2 : 1; }
+    const long want = nw == 16 ? 256 : 512;
+    int best = 1;
+    for (int mt = 1; mt <= cap; mt <<= 1) {
+        if (mt > 1 && mt / 2 >= mtiles) break;
+        const long wgs = (long)ntiles_x * ((mtiles + mt - 1) / mt);
+        if (mt == 1 || wgs >= want) best = mt;
+    }
+    return best;
+}
+
+// gemm2_kernel launcher; a == nullptr: only raise the kernel's dynamic-LDS limit (prepare_kernels, before any stream capture)
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM, int AV>
+static hipError_t launch_gemm2_av(const GemmArgs* a, hipStream_t s) {
+    constexpr size_t lds = (size_t)NW * MT * KBS * 1024 + (NORM ? (size_t)NW * MT * 16 * sizeof(float) : 0) + (gemm2_ew<NW>() ? 256 : 0);    // + the prefetch dump corner
+    auto kern = gemm2_kernel<MT, NT, EPI, NW, KBS, NORM, AV>;
+    static bool raised[MAX_DEVICES] = {};
+    if (lds > 64 * 1024 && !raised[cur_device()]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised[cur_device()] = true;
+    }
+    if (!a) return hipSuccess;
+    const int ntiles = a->packed_tiles > 0 ? a->packed_tiles / (EPI == EPI_SILU ? 2 : 1) : (a->N + 15) / 16;
+    const int gx = (EPI == EPI_SILU) ? (ntiles + NT / 2 - 1) / (NT / 2) : (ntiles + NT - 1) / NT;
+    const int gy = ((a->M + 15) / 16 + MT - 1) / MT;
+    launch_k(kern, dim3(gx, gy), dim3((NW + gemm2_ew<NW>()) * 64), lds, s, *a);
+    return hipGetLastError();
+}
+// picks AV (see gemm2_kernel): the fewest A-row instructions that cover the rows of a one-tile call
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
+static hipError_t launch_gemm2_t(const GemmArgs* a, hipStream_t s) {
+    if constexpr (MT == 1) {
+        constexpr int RPI = 64 / (KBS * 4);            // rows per A instruction: 2 (KBS 8) or 8 (KBS 2)
+        const int small = g_gemm_small_m;
+        if (!a) {
+            hipError_t e;
+            if ((e = launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, 1>(a, s)) != hipSuccess) return e;
+            if constexpr (KBS == 8) {
+                if ((e = launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, 2>(a, s)) != hipSuccess) return e;
+                if ((e = launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, 4>(a, s)) != hipSuccess) return e;
+            }
+        } else if (small && a->M <= 16) {
+            if (a->M <= RPI) return launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, 1>(a, s);
+            if constexpr (KBS == 8) {
+                if (a->M <= 2 * RPI) return launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, 2>(a, s);
+                if (a->M <= 4 * RPI) return launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, 4>(a, s);
+            }
+        }
+    }
+    return launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, KBS>(a, s);
+}
+// looped NORM form (>= 4 m-groups of 32 rows, no row gather): one workgroup per n-group, weights stationary in registers
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
+static hipError_t launch_gemm2_loop_t(const GemmArgs* a, hipStream_t s) {
+    constexpr size_t lds = (size_t)NW * MT * KBS * 1024 + (NORM ? (size_t)NW * MT * 16 * sizeof(float) : 0);
+    auto kern = gemm2_loop_kernel<MT, NT, EPI, NW, KBS, NORM>;
+    static bool raised[MAX_DEVICES] = {};
+    if (lds > 64 * 1024 && !raised[cur_device()]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised[cur_device()] = true;
+    }
+    if (!a) return hipSuccess;
+    const int ntiles = (a->N + 15) / 16;
+    const int gx = (EPI == EPI_SILU) ? (ntiles + NT / 2 - 1) / (NT / 2) : (ntiles + NT - 1) / NT;
+    const int mgroups = ((a->M + 15) / 16 + MT - 1) / MT;
+    static int split_env = -1;
+    if (split_env < 0) { const char* e = getenv(NW == 16 ? "T3_GEMM_LOOP16_SPLIT" : "T3_GEMM_LOOP_SPLIT"); split_env = e ? atoi(e) : 0; }
+    int gy = split_env > 0 ? split_env : (NW == 16 ? (NT == 2 ? 8 : 4) : 2);
+    while (gy > 1 && mgroups / gy < (NW == 16 ? 1 : 2)) --gy;      // 4 waves: every workgroup walks at least two groups (16 waves: one is enough to win, measured)
+    launch_k(kern, dim3(gx, gy), dim3(NW * 64), lds, s, *a);
+    return hipGetLastError();
+}
+// NORM forms (4 waves, K = 1024): MT in {1, 2}, NT in {1, 2, 3, 4}
+static hipError_t launch_gemm2_norm(const GemmArgs* a, int epi, int mt, int nt, hipStream_t s) {
+#define T3_G2(E, MTV, NTV) return launch_gemm2_t<MTV, NTV, E, 4, 8, true>(a, s)
+#define T3_G2_NT(E, MTV) switch (nt) { case 1: T3_G2(E, MTV, 1); case 2: T3_G2(E, MTV, 2); case 3: T3_G2(E, MTV, 3); default: T3_G2(E, MTV, 4); }
+    if (epi == EPI_F32) { if (mt >= 2) T3_G2(EPI_F32, 2, 1); else T3_G2(EPI_F32, 1, 1); }
+    if (epi == EPI_BF16) { if (mt >= 2) { T3_G2_NT(EPI_BF16, 2) } else { T3_G2_NT(EPI_BF16, 1) } }
+    if (epi == EPI_SILU) {
+        if (mt >= 2) { if (nt == 4) T3_G2(EPI_SILU, 2, 4); else T3_G2(EPI_SILU, 2, 2); }
+        else { if (nt == 4) T3_G2(EPI_SILU, 1, 4); else T3_G2(EPI_SILU, 1, 2); }
+    }
+#undef T3_G2_NT
+#undef T3_G2
+    return hipErrorInvalidValue;
+}
+// 16-segment forms at one m-tile per workgroup: K = 1024 (o_proj, 64-wide segments) or K = 4096 (down_proj, 256-wide segments)
+static hipError_t launch_gemm2_16(const GemmArgs* a, int epi, int kbs, hipStream_t s) {
+    if (epi == EPI_RESID) return kbs == 2 ? launch_gemm2_t<1, 1, EPI_RESID, 16, 2, false>(a, s) : launch_gemm2_t<1, 1, EPI_RESID, 16, 8, false>(a, s);
+    if (epi == EPI_F32) return kbs == 2 ? launch_gemm2_t<1, 1, EPI_F32, 16, 2, false>(a, s) : launch_gemm2_t<1, 1, EPI_F32, 16, 8, false>(a, s);
+    return hipErrorInvalidValue;
+}
+void gemm_refresh_switches() { const char* ev = getenv("T3_GEMM_SMALL_M"); g_gemm_small_m = ev ? atoi(ev) : 1; }
+hipError_t prepare_gemm2() {
+    hipError_t e;
+    for (int epi : {EPI_F32, EPI_BF16, EPI_SILU})
+        for (int mt = 1; mt <= 2; ++mt)
+            for (int nt = 1; nt <= 4; ++nt)
+                if ((e = launch_gemm2_norm(nullptr, epi, mt, nt, nullptr)) != hipSuccess) return e;
+    for (int epi : {EPI_F32, EPI_RESID})
+        for (int kbs : {2, 8})
+            if ((e = launch_gemm2_16(nullptr, epi, kbs, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_t<1, 1, EPI_F32, 4, 8, false>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_t<2, 1, EPI_F32, 4, 8, false>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<2, 1, EPI_BF16, 4, 8, true>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<2, 2, EPI_SILU, 4, 8, true>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<2, 4, EPI_SILU, 4, 8, true>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 8, false>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<1, 2, EPI_RESID, 16, 2, false>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 2, false>(nullptr, nullptr)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+// epi: GemmEpi; nw: 4 (qkv / gate-up / head form) or 16 (o_proj / down_proj form); a.norm: RMSNorm folded (needs K = 1024, nw = 4)
+hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    const int nw = a.nw == 16 ? 16 : 4;
+    const bool norm = a.norm != 0;
+    if (a.K % (32 * nw) != 0 || (norm && (a.K != D || nw != 4))) return hipErrorInvalidValue;
+    {
+        // rows from which the LDS-tiled schedule takes over (0 = never).  1024: a 256-row call is a DECODE step of 128 utterances,
+        // where 128 x 64 tiles leave 32-128 workgroups (measured on the continuous-batching run of tools/bench_serving.py:
+        // 16.8 k tok/s with the switch at 256 rows, 25.0 k at 1024 or 2048).
+        // Per form since the looped schedules exist (tools/chain_proto at 320-1023 rows, us per launch looped | LDS-tiled: gate/up
+        // 24.9 | 25.8 at 384 rows, 30.6 | 28.6 at 512; qkv 16.8 | 22.0 at 512, 25.4 | 23.6 at 768; o 17.0 | 20.4 and down 34.1 | 46.5
+        // at 1023: the 16-segment fold of a 128 x 64 tile is a fixed ~18 / ~40 us): -2 = these per-form switches.
+        if (g_pgemm_min_rows == -1) { const char* e = getenv("T3_PGEMM_MIN_ROWS"); g_pgemm_min_rows = e ? atoi(e) : -2; }
+        const int pg_min = g_pgemm_min_rows != -2 ? g_pgemm_min_rows
+                         : epi == EPI_SILU ? 448 : (nw == 4 ? (a.row_index ? 1024 : 704) : (a.K == D ? 1280 : 1600));
+        if (pg_min > 0 && a.M >= pg_min) {
+            const hipError_t pe = launch_pgemm(a, epi, s);
+            if (pe != hipErrorNotSupported) return pe;
+        }
+    }
+    if (norm) {
+        // n-tiles per workgroup.  Every workgroup re-reads its rows of the activation operand, so more n-tiles per workgroup divide
+        // that traffic, as long as the grid still covers the chip: the largest tile group that leaves >= 256 workgroups (one per
+        // CU: qkv at 64 rows takes groups of 3 = 256 workgroups rather than groups of 4 = 192), else the largest that leaves >= 192
+        // (256 for gate/up).  A weight whose last tile is partial (the speech head: 513 tiles) takes part when its packed buffer
+        // was padded to a multiple of the tile group (GemmArgs::packed_tiles).
+        if (mt > 2) mt = 2;
+        {
+            // gate/up from ~130 rows on (decode steps of 65+ utterances, C4): a workgroup per (gate/up pair, half of the row groups)
+            // walks its 32-row groups with the pair's weight tiles stationary in registers.  Measured at 256 rows: 25.8 -> 18.9 us
+            // (two workgroups per n-group; one: 24.3, four: 21.0); at 128 rows 13.9 -> 13.3.  qkv loses with it (8.3 -> 12.7 us at 256
+            // rows: 32 KiB of weights per workgroup do not pay for the walk) and keeps the one-workgroup-per-tile schedule.
+            static int loop_min = -1;
+            if (loop_min < 0) { const char* e = getenv("T3_GEMM_LOOP_MIN_ROWS"); loop_min = e ? atoi(e) : 81; }
+            // two gate/up pairs per workgroup (the weights of 4 packed tiles = 128 registers stationary, 256 in all, no spill): the
+            // rows pass through LDS once per 32 output columns instead of 16.  13.3 -> 10.5 us at 128 rows, 18.9 -> 16.6 at 256
+            // (T3_GEMM_LOOP_NT=2: one pair)
+            static int loop_nt = -1;
+            if (loop_nt < 0) { const char* e = getenv("T3_GEMM_LOOP_NT"); loop_nt = e ? atoi(e) : 4; }
+            if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU && loop_nt == 4) return launch_gemm2_loop_t<2, 4, EPI_SILU, 4, 8, true>(&a, s);
+            if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_SILU) return launch_gemm2_loop_t<2, 2, EPI_SILU, 4, 8, true>(&a, s);
+            if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_BF16 && getenv("T3_GEMM_LOOP_QKV")) return launch_gemm2_loop_t<2, 1, EPI_BF16, 4, 8, true>(&a, s);
+        }
+        int nt = epi == EPI_SILU ? 2 : 1;
+        if (epi != EPI_F32 && (!a.row_index || a.packed_tiles > 0)) {
+            static int force = -1;
+            if (force < 0) { const char* e = getenv("T3_GEMM_NT"); force = e ? atoi(e) : 0; }
+            const int ntiles = a.packed_tiles > 0 ? a.packed_tiles : (a.N + 15) / 16 * (epi == EPI_SILU ? 2 : 1);      // packed weight tiles
+            const int groups = ((a.M + 15) / 16 + mt - 1) / mt;
+            const int want = epi == EPI_SILU ? 256 : 192;
+            int pick = 0;
+            // a 2 x 4 workgroup holds 32 weight tiles + 16 activation pieces in registers: one workgroup per CU.  A grid a little over
+            // 256 of those (the speech head at 64 rows: 129 x 2 = 258) would run a second, almost empty round: take the next group size
+            auto partial_round = [&](int c) { const long w = (long)(ntiles / c) * groups; return mt * c >= 8 && w > 256 && w < 512; };
+            for (int c = 4; c > nt && !pick; --c)
+                if ((epi != EPI_SILU || c % 2 == 0) && ntiles % c == 0 && (long)(ntiles / c) * groups >= 256 && !partial_round(c)) pick = c;
+            for (int c = 4; c > nt && !pick; --c)
+                if ((epi != EPI_SILU || c % 2 == 0) && ntiles % c == 0 && (long)(ntiles / c) * groups >= want) pick = c;
+            if (pick) nt = pick;
+            if (force >= 1 && force <= 4 && (epi != EPI_SILU || force % 2 == 0) && ntiles % force == 0) nt = force;
+        }
+        return launch_gemm2_norm(&a, epi, mt, nt, s);
+    }
+    if (nw == 16 && (a.K == D || a.K == F) && a.N % 16 == 0 && !a.row_index && epi == EPI_RESID) {
+        // o / down from 81 rows on (6+ m-tiles): a workgroup per (n-tile, quarter of the m-tiles) walks its m-tiles with the tile's
+        // weights stationary in registers (T3_GEMM_LOOP16_MIN_ROWS; 0 = off).  Measured, us per launch old -> looped: down 10.9 -> 8.3
+        // at 96 rows, 11.9 -> 8.5 at 128, 21.9 -> 10.2 at 192, 19.4 -> 11.9 at 256; o 7.5 -> 6.0 at 256; at 64 rows the old form wins
+        static int loop16_min = -1;
+        if (loop16_min < 0) { const char* e = getenv("T3_GEMM_LOOP16_MIN_ROWS"); loop16_min = e ? atoi(e) : 81; }
+        {
+            static int nt16 = -1;
+            if (nt16 < 0) { const char* e = getenv("T3_GEMM_LOOP16_NT"); nt16 = e ? atoi(e) : 2; }
+            // two n-tiles per workgroup and 8 workgroups per n-tile pair: o only (6.0 -> 4.7 us at 256 rows, 4.3 -> 3.7 at 128).  The down form (8 k-blocks per wave) would need 170 registers at 16 waves per
+            // workgroup (128 available): hipcc spills, and a spilled destination of an in-flight asm load is a corrupted register
+            // later (tests/test_build.py keeps every asm-load kernel at zero spills)
+            static int loop16_min_o = -1;
+            if (loop16_min_o < 0) { const char* e = getenv("T3_GEMM_LOOP16_MIN_ROWS_O"); loop16_min_o = e ? atoi(e) : (loop16_min > 0 ? 65 : 0); }     // o: 4.03 -> 3.74 us at 80 rows; at 64 rows the one-shot form wins (3.53 against 3.74)
+            if (loop16_min_o > 0 && a.M >= loop16_min_o && nt16 == 2 && a.N % 32 == 0 && a.K == D)
+                return launch_gemm2_loop_t<1, 2, EPI_RESID, 16, 2, false>(&a, s);
+        }
+        if (loop16_min > 0 && a.M >= loop16_min)
+            return a.K == D ? launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 2, false>(&a, s) : launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 8, false>(&a, s);
+    }
+    // one m-tile per workgroup, any row count (grid.y = m-tiles): o / down below the looped forms' thresholds, and the parity hooks
+    if (nw == 16 && (a.K == D || a.K == F) && a.N % 16 == 0 && !a.row_index && (epi == EPI_F32 || epi == EPI_RESID))
+        return launch_gemm2_16(&a, epi, a.K / 512, s);
+    // 4 segments without the folded norm: no engine path, the parity hook t3k_gemm only (K = 1024, fp32 out)
+    if (nw == 4 && a.K == D && !a.row_index && epi == EPI_F32)
+        return mt >= 2 ? launch_gemm2_t<2, 1, EPI_F32, 4, 8, false>(&a, s) : launch_gemm2_t<1, 1, EPI_F32, 4, 8, false>(&a, s);
+    return hipErrorInvalidValue;      // not a shape of this engine (K = 1024 | 4096; the generic round-1 kernel lives in tools/legacy/)
+}
+
+// W'[n][k] = bf16(W[n][k] * ln[k]): the load-time fold of an RMSNorm weight into the projection that consumes its output
+// (contract: DESIGN.md "RMSNorm"; the checker's fold_ln is the same arithmetic).
+void fold_norm_weight(const uint16_t* W, int N, int K, const uint16_t* ln, uint16_t* out) {
+    auto b2f = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    auto f2b = [](float f) { uint32_t u; memcpy(&u, &f, 4); if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) out[(size_t)n * K + k] = f2b(b2f(W[(size_t)n * K + k]) * b2f(ln[k]));
+}
+
+void pack_weight(const uint16_t* W, int N, int K, int Npad, uint16_t* out) {
+    const int KB = K / 32;
+    for (int nt = 0; nt < Npad / 16; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = nt * 16 + (lane & 15), k0 = kb * 32 + 8 * (lane >> 4);
+                uint16_t* o = out + (((size_t)nt * KB + kb) * 64 + lane) * 8;
+                if (n < N) memcpy(o, W + (size_t)n * K + k0, 16); else memset(o, 0, 16);
+            }
+}
+
+void pack_gate_up(const uint16_t* Wg, const uint16_t* Wu, int Fdim, int K, uint16_t* out) {
+    const int KB = K / 32; const size_t tile = (size_t)KB * 64 * 8;
+    for (int t = 0; t < Fdim / 16; ++t) {
+        pack_weight(Wg + (size_t)t * 16 * K, 16, K, 16, out + (size_t)(2 * t) * tile);
+        pack_weight(Wu + (size_t)t * 16 * K, 16, K, 16, out + (size_t)(2 * t + 1) * tile);
+    }
+}
+
+}  // namespace t3

@@ -78,7 +78,6 @@ struct EmbedArgs {
     uint16_t* h;               // [rows][1024]
     int rows;
     const int* prev_tok;       // the sampler's output array of the previous step (EMB_SPEECH_PREV)
-    unsigned* zero_words = nullptr; int n_zero = 0;     // words this launch sets to 0 (the step's hand-off state), nullable
     // The step's metadata (selection arrays + row records) as the host wrote it, in pinned host memory: this launch reads its own row
     // records from there and leaves the device copy every later launch of the step reads (no copy kernel in front of the step).
     const int4* host_meta = nullptr; int4* dev_meta = nullptr; int meta_vec = 0;      // meta_vec 16-byte pieces
@@ -115,12 +114,6 @@ struct AttnArgs {
     int force_waves = 0;       // 4 / 8: waves per (row, head) workgroup of the per-row kernel (0: by row count; parity tests check both)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
-// The qkv projection inside the fused decode attention launch (any decode row count >= 2): x = residual rows [rows][1024], wqkv = the layer's
-// packed norm-folded matrix, qkv = the [rows][3072] buffer the units publish into, sync = qkv_in_attention_sync_words(rows) uint32 words that
-// must be ZERO at launch (word 1 comes back non-zero if a workgroup gave up waiting), a = the fused-form attention arguments.
-int qkv_in_attention_sync_words(int rows);
-bool qkv_in_attention_fits(int rows, int max_chunks);
-hipError_t launch_qkv_in_attention(const uint16_t* x, const uint4* wqkv, uint16_t* qkv, unsigned* sync, const AttnArgs& a, hipStream_t s);
 // parity hook: K (as stored, i.e. rotated) and V of every row's (stream, position) read back from the paged pool -> out [rows][2][1024]
 hipError_t launch_kv_gather(const uint16_t* kv_layer, const int* rowrec, int row_stride, int rows, uint16_t* out, hipStream_t s);
 
@@ -144,6 +137,8 @@ hipError_t launch_sampler(const SampleArgs& a, hipStream_t s);
 void arm_launch_events(hipEvent_t start, hipEvent_t stop);
 bool launch_events_armed();
 hipError_t prepare_kernels();   // one-time function attributes (must run before any stream capture)
+hipError_t prepare_gemm2();     // its GEMM part (t3_gemm.hip)
+void gemm_refresh_switches();   // re-reads the measurement switches of the GEMM launchers (per engine)
 hipError_t launch_expf(const float* x, float* y, int n, hipStream_t s);
 
 // f4: batched token hand-off to the vocoder.  One workgroup per utterance applies the reference's post-filter (tts.py:300-365 +

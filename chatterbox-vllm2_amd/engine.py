@@ -53,7 +53,7 @@ class T3Stats(ct.Structure):
         ("prefill_rows", ct.c_int64), ("decode_rows", ct.c_int64),
         ("gpu_ms_total", ct.c_double), ("gpu_ms_decode", ct.c_double), ("algo_bytes_decode", ct.c_double),
         ("sum_ctx_decode", ct.c_double),
-        ("kv_blocks_total", ct.c_int64), ("kv_blocks_free", ct.c_int64), ("weight_bytes", ct.c_int64),
+        ("kv_blocks_total", ct.c_int64), ("kv_blocks_free", ct.c_int64), ("weight_bytes", ct.c_int64), ("finished_dropped", ct.c_int64),
     ]
 
 
@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "t3_create", "t3_destroy", "t3_last_error", "t3_load_tensor", "t3_finalize_weights", "t3_add_request",
     "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_get_timing", "t3_release_request", "t3_abort_request", "t3_handoff_tokens", "t3_reserve_handoff", "t3_pop_finished", "t3_debug_embeddings", "t3k_handoff",
     "t3_clean_tokens", "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_set_profile_kernel", "t3_kernel_ms",
-    "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_decode_attention", "t3k_qkv_decode_attention", "t3k_sample", "t3k_expf",
+    "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_decode_attention", "t3k_sample", "t3k_expf",
     "t3_cond_create", "t3_cond_destroy", "t3_cond_last_error", "t3_cond_load_tensor", "t3_cond_encode", "t3_cond_emotion_row",
     "t3k_ce_layernorm", "t3k_ce_linear", "t3k_ce_attention", "t3k_set_prefill_rows", "t3k_set_prefill_wide_rows",
 ]
@@ -123,7 +123,6 @@ def load_library():
     L.t3k_silu_mul_gemm.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.t3k_rope_attention.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.t3k_decode_attention.argtypes = [vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp]
-    L.t3k_qkv_decode_attention.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     L.t3k_sample.argtypes = [vp, i32, vp, ct.POINTER(T3Sampling), ct.c_float, ct.c_uint32, vp, vp]
     L.t3k_expf.argtypes = [vp, vp, i32]
     L.t3_cond_create.argtypes = [i32, ct.POINTER(vp)]
@@ -279,6 +278,7 @@ class T3Engine:
     def reserve_handoff(self, n_requests: int):
         """Keep finished utterances' ids in device memory (n_requests > 0: buffers for that many are made now) or stop doing so (0)."""
         self._chk(self.lib.t3_reserve_handoff(self.h, int(n_requests)))
+        self.keeps_device_ids = int(n_requests) > 0
 
     def pop_finished(self, cap: int = 4096) -> List[int]:
         """ids of the requests that finished since the last call, oldest first"""
@@ -395,19 +395,6 @@ def k_decode_attention(ctx_qkv: torch.Tensor, new_qkv: torch.Tensor, ctx, max_po
     out = torch.empty(steps, rows, C.HIDDEN, dtype=torch.bfloat16); kvn = torch.empty(steps, rows, 2, C.HIDDEN, dtype=torch.bfloat16)
     _chk_k(load_library().t3k_decode_attention(ctx_qkv.data_ptr(), ctx_qkv.shape[0], ctx_qkv.shape[1], new_qkv.data_ptr(), cx.ctypes.data,
                                                rows, steps, int(max_pos), int(waves), out.data_ptr(), kvn.data_ptr()), "t3k_decode_attention")
-    return out, kvn
-
-
-def k_qkv_decode_attention(ctx_qkv: torch.Tensor, h_rows: torch.Tensor, ln_w: torch.Tensor, wqkv: torch.Tensor, ctx, max_pos: int):
-    """The one-launch qkv projection + fused decode attention of small steps.  h_rows [steps, rows, 1024] bf16 residual rows, ln_w [1024],
-    wqkv [3072, 1024] -> (out [steps, rows, 1024] bf16, kv_new [steps, rows, 2, 1024] bf16); ctx_qkv / ctx as k_decode_attention."""
-    ctx_qkv, h_rows, ln_w, wqkv = _bf(ctx_qkv), _bf(h_rows), _bf(ln_w), _bf(wqkv)
-    cx = np.ascontiguousarray(np.asarray(ctx, dtype=np.int32))
-    steps, rows = h_rows.shape[0], h_rows.shape[1]
-    assert h_rows.shape[2] == C.HIDDEN and tuple(wqkv.shape) == (3072, C.HIDDEN) and len(cx) == rows
-    out = torch.empty(steps, rows, C.HIDDEN, dtype=torch.bfloat16); kvn = torch.empty(steps, rows, 2, C.HIDDEN, dtype=torch.bfloat16)
-    _chk_k(load_library().t3k_qkv_decode_attention(ctx_qkv.data_ptr(), ctx_qkv.shape[0], ctx_qkv.shape[1], h_rows.data_ptr(), ln_w.data_ptr(), wqkv.data_ptr(),
-                                                   cx.ctypes.data, rows, steps, int(max_pos), out.data_ptr(), kvn.data_ptr()), "t3k_qkv_decode_attention")
     return out, kvn
 
 

@@ -185,8 +185,11 @@ class LLM:
         queued: List[int] = []
         uid0 = self._next_uid
         # ids stay in device memory for the hand-off only when asked for; free buffers for this call's requests are made now, outside
-        # the step loop (requests kept by an earlier call hold theirs until handoff_tokens releases them)
-        self.engine.reserve_handoff(len(prompts) if keep_for_handoff else 0)
+        # the step loop (requests kept by an earlier call hold theirs until handoff_tokens releases them).  A caller that switched the
+        # retention on itself (T3Engine.reserve_handoff) keeps it: this call touches the flag only when it needs it and puts it back.
+        kept_before = getattr(self.engine, "keeps_device_ids", False)
+        if keep_for_handoff:
+            self.engine.reserve_handoff(len(prompts))
         try:
             self._queue(prompts, sps, uids, metas, queued)
         except Exception:
@@ -203,6 +206,9 @@ class LLM:
                 except Exception:
                     pass
             raise
+        finally:
+            if keep_for_handoff and not kept_before:
+                self.engine.reserve_handoff(0)      # finished requests keep the buffers they hold; no new ones are made
         outs = []
         for rid, text, final in metas:
             toks, fr = self.engine.get_output(rid)

@@ -97,6 +97,7 @@ typedef struct {
     double sum_ctx_decode;         /* sum over decode rows of context length */
     int64_t kv_blocks_total, kv_blocks_free;
     int64_t weight_bytes;
+    int64_t finished_dropped;      /* ids t3_pop_finished will never return: the queue of finished ids holds 4 * max_seqs + 4096 entries and drops the oldest beyond that (a caller that never pops must not grow it) */
 } T3Stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
@@ -184,7 +185,11 @@ int t3_stats(T3Handle h, T3Stats* out);
 int t3_reset_stats(T3Handle h);
 /* Average duration (ms) per launch of each kernel class over decode-only steps since the last reset,
  * measured with HIP events on the engine's stream when profiling is on (t3_set_profile).
- * names: "gemm_qkv","gemm_o","gemm_gateup","gemm_down","gemm_head","attention","rope_kv","embed","sampler". */
+ * names: "gemm_qkv","gemm_o","gemm_gateup","gemm_down","gemm_head","attention","rope_kv","embed","sampler".
+ * Single-kernel launches (the decode GEMM forms, the fused / per-row attention, embed, sampler) are timed by the dispatch's own start / stop
+ * events (what rocprofv3 reports); launchers that issue several kernels (prefill-sized GEMMs with their row-statistic pass, the tile attention
+ * with its per-row head, rope_kv) are bracketed by two event records, ~2-3 us more per launch.  Only decode-only steps are accumulated, where every
+ * class is of the first kind. */
 int t3_set_profile(T3Handle h, int32_t on);
 /* Restrict the events to ONE kernel class (name as above; NULL or "" = every class): the other launches of the step then run
  * undisturbed, so the class's average duration is not inflated by its neighbours' event packets. */
@@ -217,7 +222,8 @@ int t3k_ce_linear(const float* x /*[M][K]*/, const float* W /*[N][K]*/, const fl
 int t3k_ce_attention(const float* q /*[nq][1024]*/, const float* k /*[nk][1024]*/, const float* v, float* out /*[nq][1024]*/, int32_t nq, int32_t nk);
 
 /* ---- kernel-level entry points (host buffers in, host buffers out; used by the parity tests) ----
- * Each runs exactly the kernel the engine uses, on the current device, and waits for it.      */
+ * Each runs exactly the kernel the engine uses, on the current device, and waits for it.
+ * t3k_gemm: the engine's K only -- 1024 with 4 segments; 1024 or 4096 with 16 (N a multiple of 16 there); anything else is T3_E_INVALID. */
 int t3k_gemm(const void* x_bf16 /*[M][K]*/, const void* w_bf16 /*[N][K]*/, int32_t M, int32_t K, int32_t N,
              float* out_f32 /*[M][N]*/, int32_t mt /*0 = auto*/, int32_t nw /*K segments: 4, or 16 = o_proj/down_proj form*/);
 /* RMSNorm folded into the projection (qkv / gate-up / speech-head form): out[r] = rstd * GEMM(bf16(h[row_index[r]] * ln_w), W);
@@ -244,12 +250,6 @@ int t3k_rope_attention(const void* qkv_bf16, const int32_t* row_stream, const in
  * out bf16 [steps][rows][1024]; kv_new (nullable) bf16 [steps][rows][2][1024] = K (rotated) and V of the written positions, read back. */
 int t3k_decode_attention(const void* ctx_qkv_bf16, int32_t n_content, int32_t content_rows, const void* new_qkv_bf16, const int32_t* ctx,
                          int32_t rows, int32_t steps, int32_t max_pos, int32_t waves, void* out_bf16, void* kv_new_bf16);
-/* The qkv projection computed INSIDE the fused decode attention launch (any row count >= 2): as t3k_decode_attention, but launch s takes the
- * residual rows h_rows[s][r] ([steps][rows][1024] bf16), the RMSNorm weight ln_w [1024] and the layer's qkv matrix wqkv [3072][1024] (q, k, v
- * rows in that order, as the checkpoint holds them); the launch's first workgroups project q | k | v in units of (16 rows, head, q|k|v) and
- * hand them to the attention workgroups through flags.  T3_E_DEVICE if a workgroup gave up waiting for a unit. */
-int t3k_qkv_decode_attention(const void* ctx_qkv_bf16, int32_t n_content, int32_t content_rows, const void* h_rows_bf16, const void* ln_w_bf16,
-                             const void* wqkv_bf16, const int32_t* ctx, int32_t rows, int32_t steps, int32_t max_pos, void* out_bf16, void* kv_new_bf16);
 /* CFG + sampler: logits bf16 [2][ldl] (cond row, uncond row), counts uint16 [8194] (updated). */
 int t3k_sample(const void* logits2_bf16, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg,
                uint32_t step, int32_t* token_out, float* logits_out_8194 /*nullable*/);

@@ -39,7 +39,7 @@ def test_struct_layouts_match_the_header():
     assert engine.T3Sampling.seed.offset == 40 and engine.T3Sampling.uid.offset == 48
     assert ctypes.sizeof(engine.T3EngineConfig) == 56 and engine.T3EngineConfig.kv_bytes.offset == 24
     assert ctypes.sizeof(engine.T3StepResult) == 24 + 64 * 8
-    assert ctypes.sizeof(engine.T3Stats) == 12 * 8
+    assert ctypes.sizeof(engine.T3Stats) == 13 * 8
 
 
 def test_no_gpu_means_loud_failure():

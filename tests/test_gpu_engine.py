@@ -93,7 +93,7 @@ def test_batch_invariance_and_continuous_batching(E, oracle, tiny_engine, tiny_o
     assert st.kv_blocks_free == st.kv_blocks_total      # every block returned
 
 
-@pytest.mark.parametrize("n_groups,eager", [(1, True), (3, False), (4, True)])        # (1, False) is every other test's configuration
+@pytest.mark.parametrize("n_groups,eager", [(1, True), (2, False), (3, False), (4, True)])        # (1, False) is every other test's configuration
 def test_groups_and_graph_replay_do_not_change_ids(E, oracle, tiny_weights, tiny_oracle, cond, n_groups, eager):
     """Concurrent utterance groups (separate streams) and hipGraph replay are scheduling only: every stream still
     equals its single-utterance oracle stream.  Requests finish at different steps, so graphs are re-captured."""

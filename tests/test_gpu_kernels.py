@@ -30,8 +30,8 @@ def test_expf_bit_exact(E, oracle):
 
 
 @pytest.mark.parametrize("M,K,N,mt", [(2, 1024, 3072, 0), (1, 1024, 48, 1), (16, 1024, 1024, 0), (17, 1024, 64, 2),
-                                        (64, 1024, 3072, 0), (64, 1024, 1024, 1), (64, 4096, 1024, 0), (64, 1024, 8194, 4),
-                                        (200, 1024, 512, 8), (256, 4096, 256, 4), (33, 128, 16, 0)])
+                                        (64, 1024, 3072, 0), (64, 1024, 1024, 1), (64, 1024, 8194, 2),
+                                        (200, 1024, 512, 2), (33, 1024, 16, 0)])      # the engine's 4-segment K (1024); other K: tools/legacy
 def test_gemm_bit_exact(E, oracle, M, K, N, mt):
     x = rand_bf16(M, K, seed=M + K); W = rand_bf16(N, K, seed=N, scale=0.05)
     got = E.k_gemm(x, W, mt)
@@ -42,7 +42,7 @@ def test_gemm_bit_exact(E, oracle, M, K, N, mt):
     assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("M,K,N,mt", [(64, 1024, 1024, 0), (64, 4096, 1024, 0), (3, 4096, 48, 1), (130, 1024, 64, 4), (16, 512, 32, 0), (2, 1024, 1024, 0)])
+@pytest.mark.parametrize("M,K,N,mt", [(64, 1024, 1024, 0), (64, 4096, 1024, 0), (3, 4096, 48, 1), (130, 1024, 64, 4), (16, 4096, 32, 0), (2, 1024, 1024, 0)])
 def test_gemm_16_segments_bit_exact(E, oracle, M, K, N, mt):
     """o_proj / down_proj form: 16 K-segments (16 waves) in one workgroup, groups of four folded ((G0+G1)+G2)+G3."""
     x = rand_bf16(M, K, seed=M + K + 1); W = rand_bf16(N, K, seed=N + 1, scale=0.05)
@@ -268,30 +268,6 @@ def test_fused_decode_attention_256_rows(E, oracle):
     want, kv_want = _oracle_decode_attention(oracle, ctx_qkv, new_qkv, ctx, max_pos)
     assert_bit_equal(kv_got, kv_want, "newest K / V, 256 rows")
     assert_bit_equal(got, want, "fused decode attention, 256 rows")
-
-
-@pytest.mark.parametrize("rows", [2, 33, 64, 256])
-def test_qkv_projection_inside_the_attention_launch(E, oracle, rows):
-    """qkv_in_attention_kernel: the first workgroups of the attention launch project q | k | v in units of (16 rows, head, q|k|v) -- the MFMA
-    chains, fold order and rstd epilogue of gemm2_kernel -- and hand them to the attention workgroups through flags (write-through stores,
-    sc1 loads).  Against oracle.norm_gemm -> bf16 -> oracle.rope + oracle.attn_row and against the two-launch path on the same inputs:
-    contexts at every chunk / block boundary up to max_model_len 1000, ragged row counts (a partial last m-tile), two consecutive launches
-    (stale lines of the q / k / v buffer from the first launch sit in L1 when the second one reads it), the written K / V read back."""
-    max_pos = 1001
-    ctx_qkv = rand_bf16(2, 998, 3072, seed=40 + rows)
-    ln = (rand_bf16(1024, seed=9) + 1.0).to(torch.bfloat16); W = rand_bf16(3072, 1024, seed=11, scale=0.05)
-    for j in range(len(DECODE_CTX) if rows <= 9 else 2):
-        ctx = [DECODE_CTX[(r + j) % len(DECODE_CTX)] for r in range(rows)]
-        h = rand_bf16(2, rows, 1024, seed=500 * rows + j, scale=2.0)
-        new_qkv = torch.stack([oracle.norm_gemm(h[s], ln, W).to(torch.bfloat16) for s in range(2)])
-        got, kv_got = E.k_qkv_decode_attention(ctx_qkv, h, ln, W, ctx, max_pos)
-        sep, kv_sep = E.k_decode_attention(ctx_qkv, new_qkv, ctx, max_pos, 0)              # projection and attention as two launches
-        assert_bit_equal(kv_got, kv_sep, f"newest K / V, one launch vs two, rows={rows} launch {j}")
-        assert_bit_equal(got, sep, f"one launch vs projection + attention as two launches, rows={rows} launch {j}")
-        if rows <= 64:
-            want, kv_want = _oracle_decode_attention(oracle, ctx_qkv, new_qkv, ctx, max_pos)
-            assert_bit_equal(kv_got, kv_want, f"newest K / V against the oracle, rows={rows} launch {j}")
-            assert_bit_equal(got, want, f"qkv inside the attention launch against the oracle, rows={rows} launch {j}")
 
 
 def test_prefill_attention_beyond_tile_lds(E, oracle):

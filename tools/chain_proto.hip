@@ -3,7 +3,7 @@
 // replayed from a hipGraph.  Build:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt tools/chain_proto.hip -o tools/chain_proto
 // args: rows (default 64), repeats (default 20)
-#include "../chatterbox-vllm2_amd/csrc/t3_kernels.hip"
+#include "../chatterbox-vllm2_amd/csrc/t3_gemm.hip"
 #include "chain_kernel.hip"
 #include <algorithm>
 #include <cstdio>

@@ -2,7 +2,7 @@
 // layers of distinct weights, back to back on one stream).  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
 // -fhip-fp32-correctly-rounded-divide-sqrt -std=c++17 -DT3_GEMM_CLK tools/gemm_clk.hip -o tools/gemm_clk
 // Reports the stamps of gemm2_kernel (the schedule the engine runs at <= 64-80 rows): entry, A staged, first weights, last MFMA, barrier, store.
-#include "../chatterbox-vllm2_amd/csrc/t3_kernels.hip"
+#include "../chatterbox-vllm2_amd/csrc/t3_gemm.hip"
 #include <algorithm>
 #include <cstdio>
 #include <vector>
