@@ -214,8 +214,18 @@ extern "C" int t3k_decode_attention(const void* ctx_qkv, int32_t n_content, int3
     return T3_OK;
 }
 
+static int sample_impl(const void* logits2, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg, uint32_t step,
+                       int32_t* token_out, float* logits_out, uint8_t* keep_out);
 extern "C" int t3k_sample(const void* logits2, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg, uint32_t step,
-                          int32_t* token_out, float* logits_out) {
+                          int32_t* token_out, float* logits_out) { return sample_impl(logits2, ldl, counts, sp, cfg, step, token_out, logits_out, nullptr); }
+/* t3k_sample + the SUPPORT of the draw: keep_out [8194] = 1 where the masks (penalties -> /T -> min-p -> top-k -> top-p) leave the id drawable */
+extern "C" int t3k_sample_support(const void* logits2, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg, uint32_t step,
+                                  int32_t* token_out, uint8_t* keep_out) {
+    if (!keep_out) return T3_E_INVALID;
+    return sample_impl(logits2, ldl, counts, sp, cfg, step, token_out, nullptr, keep_out);
+}
+static int sample_impl(const void* logits2, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg, uint32_t step,
+                       int32_t* token_out, float* logits_out, uint8_t* keep_out) {
     if (!logits2 || !counts || !sp || !token_out || ldl < V) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
     std::vector<uint16_t> cpad(VPAD, 0);
@@ -225,8 +235,11 @@ extern "C" int t3k_sample(const void* logits2, int32_t ldl, uint16_t* counts, co
     K_TRY(dl.from(logits2, (size_t)2 * ldl * 2)); K_TRY(dc.from(cpad.data(), VPAD * 2)); K_TRY(dsp.from(sp, sizeof(T3Sampling)));
     K_TRY(dsel.from(&sel, sizeof(sel))); K_TRY(dtok.alloc(4, true)); K_TRY(ddbg.alloc((size_t)V * 4, true));
     SampleArgs sa{dl.as<uint16_t>(), ldl, dsel.as<int4>(), dc.as<uint16_t>(), dsp.as<T3Sampling>(), cfg, dtok.as<int>(), ddbg.as<float>(), 1};
+    DevBuf dkeep;
+    if (keep_out) { K_TRY(dkeep.alloc(V, true)); sa.dbg_keep = dkeep.as<unsigned char>(); }
     K_TRY(launch_sampler(sa, nullptr));
     K_TRY(hipDeviceSynchronize());
+    if (keep_out) K_TRY(hipMemcpy(keep_out, dkeep.p, V, hipMemcpyDeviceToHost));
     K_TRY(hipMemcpy(token_out, dtok.p, 4, hipMemcpyDeviceToHost));
     K_TRY(hipMemcpy(cpad.data(), dc.p, VPAD * 2, hipMemcpyDeviceToHost));
     memcpy(counts, cpad.data(), V * 2);

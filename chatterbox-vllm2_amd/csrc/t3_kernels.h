@@ -130,6 +130,7 @@ struct SampleArgs {
     int* hist = nullptr;       // nullable: [max_seqs][hist_cap] speech-space ids of every utterance, kept on the device (f4 hand-off)
     int hist_cap = 0;
     int* out_tok_host = nullptr;   // nullable: [n] in pinned host memory, written beside out_tok (no copy kernel behind the step)
+    unsigned char* dbg_keep = nullptr;   // nullable (parity hook t3k_sample_support): [max_seqs][V] 1 where the draw can return the id
 };
 hipError_t launch_sampler(const SampleArgs& a, hipStream_t s);
 // Profile mode: the next single-kernel launch of this thread (decode GEMM forms, fused / per-row attention, embed, sampler) takes these as

@@ -351,6 +351,10 @@ __global__ __launch_bounds__(STH) void sampler_kernel(SampleArgs a) {
             }
         }
         T3_CLK(7);
+        if (a.dbg_keep) {                                   // parity hook: the support of the draw (what the masks left)
+#pragma unroll
+            for (int i = 0; i < SPT; ++i) if (v0 + i < V) a.dbg_keep[(size_t)slot * V + v0 + i] = wr[i] != 0;
+        }
         // ---- draw
         unsigned long long mine = 0;
 #pragma unroll
@@ -379,6 +383,7 @@ __global__ __launch_bounds__(STH) void sampler_kernel(SampleArgs a) {
     }
     if (tid == 0) {
         token = token < 0 ? 0 : (token >= V ? V - 1 : token);       // counts[] / speech_emb[] are indexed with it
+        if (a.dbg_keep && greedy) a.dbg_keep[(size_t)slot * V + token] = 1;      // (zeroed by the caller)
         a.out_tok[u] = token;
         if (a.out_tok_host) a.out_tok_host[u] = token;
         if (a.hist && (int)step < a.hist_cap) a.hist[(size_t)slot * a.hist_cap + step] = token;      // the utterance's ids stay on the device

@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "t3_create", "t3_destroy", "t3_last_error", "t3_load_tensor", "t3_finalize_weights", "t3_add_request",
     "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_get_timing", "t3_release_request", "t3_abort_request", "t3_handoff_tokens", "t3_reserve_handoff", "t3_pop_finished", "t3_debug_embeddings", "t3k_handoff",
     "t3_clean_tokens", "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_set_profile_kernel", "t3_kernel_ms",
-    "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_decode_attention", "t3k_sample", "t3k_expf",
+    "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_decode_attention", "t3k_sample", "t3k_sample_support", "t3k_expf",
     "t3_cond_create", "t3_cond_destroy", "t3_cond_last_error", "t3_cond_load_tensor", "t3_cond_encode", "t3_cond_emotion_row",
     "t3k_ce_layernorm", "t3k_ce_linear", "t3k_ce_attention", "t3k_set_prefill_rows", "t3k_set_prefill_wide_rows",
 ]
@@ -124,6 +124,7 @@ def load_library():
     L.t3k_rope_attention.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.t3k_decode_attention.argtypes = [vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp]
     L.t3k_sample.argtypes = [vp, i32, vp, ct.POINTER(T3Sampling), ct.c_float, ct.c_uint32, vp, vp]
+    L.t3k_sample_support.argtypes = [vp, i32, vp, ct.POINTER(T3Sampling), ct.c_float, ct.c_uint32, vp, vp]
     L.t3k_expf.argtypes = [vp, vp, i32]
     L.t3_cond_create.argtypes = [i32, ct.POINTER(vp)]
     L.t3_cond_destroy.argtypes = [vp]
@@ -407,6 +408,17 @@ def k_sample(logits2: torch.Tensor, counts: torch.Tensor, sp: T3Sampling, cfg: f
     _chk_k(load_library().t3k_sample(logits2.data_ptr(), logits2.shape[1], counts.data_ptr(), ct.byref(sp), ct.c_float(cfg),
                                      ct.c_uint32(step), ct.byref(tok), lg.data_ptr()), "t3k_sample")
     return int(tok.value), lg
+
+
+def k_sample_support(logits2: torch.Tensor, counts: torch.Tensor, sp: T3Sampling, cfg: float, step: int):
+    """k_sample plus the support of the draw -> (token, keep [8194] bool): the ids the masks leave drawable"""
+    logits2 = _bf(logits2)
+    assert counts.dtype == torch.uint16 and counts.numel() == C.SPEECH_VOCAB
+    tok = ct.c_int32(0)
+    keep = torch.zeros(C.SPEECH_VOCAB, dtype=torch.uint8)
+    _chk_k(load_library().t3k_sample_support(logits2.data_ptr(), logits2.shape[1], counts.data_ptr(), ct.byref(sp), ct.c_float(cfg),
+                                             ct.c_uint32(step), ct.byref(tok), keep.data_ptr()), "t3k_sample_support")
+    return int(tok.value), keep.bool()
 
 
 def k_handoff(ids, text_token_count: int, flags: int = 1, ld: int = 0):

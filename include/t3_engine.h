@@ -253,6 +253,10 @@ int t3k_decode_attention(const void* ctx_qkv_bf16, int32_t n_content, int32_t co
 /* CFG + sampler: logits bf16 [2][ldl] (cond row, uncond row), counts uint16 [8194] (updated). */
 int t3k_sample(const void* logits2_bf16, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg,
                uint32_t step, int32_t* token_out, float* logits_out_8194 /*nullable*/);
+/* t3k_sample plus the SUPPORT of its draw: keep_out [8194] = 1 where penalties -> /T -> min-p -> top-k -> top-p leave the id drawable
+ * (greedy: the one id).  Parity hook of the randomized mask test (tests/vllm_masks.py). */
+int t3k_sample_support(const void* logits2_bf16, int32_t ldl, uint16_t* counts, const T3Sampling* sp, float cfg,
+                       uint32_t step, int32_t* token_out, uint8_t* keep_out_8194);
 int t3k_expf(const float* x, float* y, int32_t n);
 /* the hand-off kernel on host buffers (one utterance): out [ld] padded with 0, *len = kept tokens */
 int t3k_handoff(const int32_t* speech_ids, int32_t n, int32_t text_token_count, int32_t flags, int32_t* out, int32_t ld, int32_t* len);

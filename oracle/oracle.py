@@ -80,6 +80,7 @@ def lib():
         L.orc_cfg_logits.argtypes = [vp, vp, vp, f32, vp, vp, vp]
         L.orc_philox.argtypes = [ct.c_uint32] * 6 + [vp]
         L.orc_sample.restype = i32; L.orc_sample.argtypes = [vp, vp, ct.POINTER(Sampling), ct.c_uint32]
+        L.orc_sample_support.restype = i32; L.orc_sample_support.argtypes = [vp, vp, ct.POINTER(Sampling), ct.c_uint32, vp]
         L.orc_prompt_embeds.restype = i32; L.orc_prompt_embeds.argtypes = [vp, vp, i32, vp, vp, vp]
         L.orc_decode_embed.restype = i32; L.orc_decode_embed.argtypes = [vp, i32, i32, vp]
         L.orc_generate.restype = i32
@@ -170,6 +171,14 @@ def philox(c, k):
 def sample(logits: torch.Tensor, counts: torch.Tensor, sp: Sampling, step: int) -> int:
     logits = logits.to(torch.float32).contiguous(); counts = counts.to(torch.uint16).contiguous()
     return int(lib().orc_sample(_p(logits), _p(counts), ct.byref(sp), step))
+
+
+def sample_support(logits: torch.Tensor, counts: torch.Tensor, sp: Sampling, step: int = 0):
+    """(token, keep [8194] bool): the draw and the set of ids the draw can return (what the masks leave)."""
+    logits = logits.to(torch.float32).contiguous(); counts = counts.to(torch.uint16).contiguous()
+    keep = torch.zeros(8194, dtype=torch.uint8)
+    tok = int(lib().orc_sample_support(_p(logits), _p(counts), ct.byref(sp), step, _p(keep)))
+    return tok, keep.bool()
 
 
 # ---------------------------------------------------------------- model-level

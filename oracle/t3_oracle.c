@@ -17,8 +17,9 @@
  * (pyproject.toml:29), which is NOT in /root/reference and not installable here, and the
  * reference has no tests or golden vectors for this path:  PARITY UNPINNED by the reference
  * itself.  The oracle is pinned instead against (a) transformers.LlamaModel on the same
- * weights (tests/test_oracle_vs_hf.py), (b) the reference's importable leaf modules
- * (tests/golden/make_golden.py), (c) committed golden token streams.
+ * weights (tests/hf_gate.py: the tolerances; tests/test_oracle.py: the live and the committed-vector gates), (b) outputs of the
+ * reference's own importable code (tests/golden/make_golden.py), (c) committed golden token streams, (d) for the sampler's masks
+ * an independent restatement of vLLM's documented order over random cases (tests/test_oracle.py::test_sampler_support_*).
  *
  * NUMERICS CONTRACT (DESIGN.md "Numerics contract"): every rounding point and every
  * floating-point summation ORDER below is part of the specification.  The HIP kernels
@@ -41,7 +42,7 @@
 #define T3_TEXT_POS 2050   /* t3.py:280 */
 #define T3_SPEECH_POS 4100 /* t3.py:283 */
 #define T3_EPS 1e-5f       /* config.json:20 */
-#define T3_CHUNK 64        /* attention chunk == KV block, in tokens */
+#define T3_CHUNK 64        /* attention chunk in tokens (numerics contract; the product's physical KV block is 256 tokens = 4 chunks) */
 
 /* ------------------------------------------------------------------ scalar helpers */
 static inline float bf2f(uint16_t b) {
@@ -574,8 +575,9 @@ typedef struct {
     int32_t _pad;
 } OrcSampling;
 
-int orc_sample(const float* logits_in, const uint16_t* counts /* [8194] generated-token counts */,
-               const OrcSampling* sp, uint32_t step) {
+/* keep_out (nullable): [8194] the SUPPORT of the draw -- 1 where the token can be returned (greedy: the one id).  The support is
+ * what vLLM's masks decide; tests/test_oracle.py compares it with an independent restatement of those masks over random cases. */
+static int orc_sample_impl(const float* logits_in, const uint16_t* counts, const OrcSampling* sp, uint32_t step, uint8_t* keep_out) {
     static float l[T3_V]; static uint64_t w[T3_V]; static uint8_t keep[T3_V];
     for (int v = 0; v < T3_V; ++v) {
         float x = logits_in[v];
@@ -588,6 +590,7 @@ int orc_sample(const float* logits_in, const uint16_t* counts /* [8194] generate
     }
     if (sp->temperature < 1e-5f) {           /* greedy: first maximum */
         int best = 0; for (int v = 1; v < T3_V; ++v) if (l[v] > l[best]) best = v;
+        if (keep_out) { memset(keep_out, 0, T3_V); keep_out[best] = 1; }
         return best;
     }
     float mx = -INFINITY;
@@ -635,6 +638,7 @@ int orc_sample(const float* logits_in, const uint16_t* counts /* [8194] generate
         }
     }
     uint64_t Wk = 0; for (int v = 0; v < T3_V; ++v) if (keep[v]) Wk += w[v];
+    if (keep_out) memcpy(keep_out, keep, T3_V);
     if (Wk == 0) return (sp->stop_token >= 0 && sp->stop_token < T3_V) ? sp->stop_token : 0;   /* no mass at all (NaN logits): end the utterance */
     uint32_t rnd[4];
     orc_philox(step, (uint32_t)sp->uid, (uint32_t)(sp->uid >> 32), 0, (uint32_t)sp->seed, (uint32_t)(sp->seed >> 32), rnd);
@@ -643,6 +647,11 @@ int orc_sample(const float* logits_in, const uint16_t* counts /* [8194] generate
     uint64_t cum = 0; int last = 0;
     for (int v = 0; v < T3_V; ++v) if (keep[v]) { cum += w[v]; last = v; if (cum > target) return v; }
     return last;
+}
+int orc_sample(const float* logits_in, const uint16_t* counts /* [8194] generated-token counts */,
+               const OrcSampling* sp, uint32_t step) { return orc_sample_impl(logits_in, counts, sp, step, NULL); }
+int orc_sample_support(const float* logits_in, const uint16_t* counts, const OrcSampling* sp, uint32_t step, uint8_t* keep_out /* [8194] */) {
+    return orc_sample_impl(logits_in, counts, sp, step, keep_out);
 }
 
 /* ------------------------------------------------------------------ prompt embeddings  (t3.py:542-561)

@@ -315,6 +315,21 @@ def test_sampler_bit_exact(E, oracle, kw):
             assert tok == want, (kw, trial, step, tok, want)
 
 
+def test_sampler_support_on_the_device(E, oracle):
+    """VERDICT r3 item 4, device half: on 64 of the 2 000 random cases of tests/test_oracle.py::test_sampler_support_matches_vllm_mask_
+    restatement the HIP sampler's SUPPORT (the ids its masks leave drawable, t3k_sample_support) equals the oracle's bit for bit and
+    passes the same comparison with the independent restatement of vLLM's masks (tests/vllm_masks.py); the drawn id equals the oracle's."""
+    from vllm_masks import check_support, sampler_case
+    for i in range(0, 2000, 31)[:64]:
+        lg, cnt, kw = sampler_case(i)
+        l2 = torch.zeros(2, 8208); l2[0, :8194] = lg; l2[1, :8194] = lg          # cond == uncond: CFG returns the row itself (bf16-valued)
+        tok, keep = E.k_sample_support(l2.to(torch.bfloat16), cnt.to(torch.uint16), E.make_sampling(seed=i, **kw), 0.5, i % 5)
+        otok, okeep = oracle.sample_support(lg, cnt, oracle.make_sampling(seed=i, **kw), i % 5)
+        assert tok == otok, (i, kw, tok, otok)
+        assert torch.equal(keep, okeep), (i, kw, int(keep.sum()), int(okeep.sum()))
+        check_support(i, lg, cnt, kw, tok, keep)
+
+
 def test_sampler_ties_and_degenerate(E, oracle):
     """bf16 logits tie constantly; all-equal logits and a single dominant logit are the edge cases."""
     for fill, spike in ((0.0, None), (1.0, (4321, 30.0)), (-3.0, (0, 1.0))):
