@@ -21,6 +21,13 @@ batching; with N GPUs the stream is submitted N times (distinct utterance ids) a
 (~499 requests per rank: weak scaling).  A "step" there = one engine step (decode rows of the running utterances + prefill rows of
 the admitted ones); K timed steps after W warmup steps, then the stream runs to its end for the e2e / RTF figures.
 
+`--workload c2` (BASELINE.json configs[1], the setting of the reference's only published number, README.md:313-325): English vocabulary
+704, ONE utterance (the 20-word sentence of C1, T = 108), max_model_len = 400 -> G = 292 tokens; a step = one decode step of the
+utterance (2 CFG rows); default 200 timed steps centred on decode step 146.
+
+Every line carries step_ms_p50 / p90 / p99: the distribution of the timed steps' own durations (t3_step_times: from the completion of
+the step before to the step's completion, on the host clock that waits on the step's event).
+
   python bench.py --gpus N --steps K --warmup W
 N > 1: one rank per GPU over RCCL.  Launched without WORLD_SIZE in the environment, this process starts the N ranks itself
 (`python -m torch.distributed.run ... bench.py`, before it touches the GPU) and relays rank 0's JSON line.
@@ -44,36 +51,53 @@ S3_TOKEN_RATE = 25.0           # speech tokens per second of audio (reference s3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=800)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps; 0 = 800 (c3, c4) / 200 (c2)")
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=("c3", "c4"), default="c3")
-    ap.add_argument("--batch", type=int, default=0, help="utterances (c3) / slots (c4) per GPU; 0 = 32 / 128")
+    ap.add_argument("--workload", choices=("c2", "c3", "c4"), default="c3")
+    ap.add_argument("--batch", type=int, default=0, help="utterances (c3) / slots (c4) per GPU; 0 = 32 / 128 (c2: always 1)")
     ap.add_argument("--layers", type=int, default=30)
-    ap.add_argument("--max-model-len", type=int, default=1000)
+    ap.add_argument("--max-model-len", type=int, default=0, help="0 = 1000 (c3, c4) / 400 (c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     a = ap.parse_args()
+    if a.workload == "c2":
+        a.batch = 1
     if a.batch <= 0:
         a.batch = 32 if a.workload == "c3" else 128
+    if a.max_model_len <= 0:
+        a.max_model_len = 400 if a.workload == "c2" else 1000
+    if a.steps <= 0:
+        a.steps = 200 if a.workload == "c2" else 800
+    a.vocab = 704 if a.workload == "c2" else 2454
     return a
 
 
 T_EN, T_ES = 116, 141             # prompt lengths of the two C3 utterances
+T_C2 = 108                        # C1 / C2: the 20-word English sentence under the English tokenizer
+
+
+def longest_prompt(args):
+    return T_C2 if args.workload == "c2" else T_ES
 
 
 def plan_window(args):
     """(fast-forward steps, first timed decode step, last timed decode step + 1): the timed window is centred on the run midpoint."""
-    g_min = args.max_model_len - T_ES - 3                 # decode steps every utterance of the batch can take
+    g_min = args.max_model_len - longest_prompt(args) - 3  # decode steps every utterance of the batch can take
     if args.steps + args.warmup > g_min:
         sys.exit(f"steps + warmup must be <= {g_min} for this workload")
-    centre = (args.max_model_len - T_ES) // 2
+    centre = (args.max_model_len - longest_prompt(args)) // 2
     ff = max(0, min(centre - args.steps // 2 - args.warmup, g_min - args.steps - args.warmup))
     first = 1 + ff + args.warmup                         # the prefill step samples token 0
     return ff, first, first + args.steps
 
 
 def workload_string(args, first, last):
+    if args.workload == "c2":
+        tag = "C2" if (args.max_model_len, args.layers) == (400, 30) else "custom (NOT a BASELINE.json config)"
+        return (f"{tag}: t3-model (English, {args.layers}-layer Llama_520M, vocab 704), batch 1 (the 20-word sentence of C1, T={T_C2}), "
+                f"max_model_len={args.max_model_len} -> G={args.max_model_len - T_C2} tokens, CFG dual stream (2 rows/step), temperature 0.8 / top-p 0.8 / "
+                f"repetition penalty 2.0, stop id masked; timed window = decode steps [{first}, {last}) of the utterance")
     b_en = args.batch // 2
     is_c3 = (args.batch, args.max_model_len, args.layers) == (32, 1000, 30)
     tag = "C3" if is_c3 else "custom (NOT a BASELINE.json config)"
@@ -82,8 +106,21 @@ def workload_string(args, first, last):
             f"repetition penalty 2.0, stop id masked; timed window = decode steps [{first}, {last}) of every utterance")
 
 
+def check_gpu_count(world):
+    """RCCL cannot build a communicator over duplicate devices: say so here, in the bench's own words and before any GPU call, rather than
+    from inside init_process_group (torch.cuda.device_count() does not initialise the GPU on this image)."""
+    if world <= 1 or os.environ.get("T3_BENCH_BACKEND", "nccl") != "nccl":
+        return
+    import torch
+    ndev = torch.cuda.device_count()
+    if world > ndev:
+        sys.exit(f"bench.py --gpus {world}: this node exposes {ndev} GPU(s) and the nccl (RCCL) backend needs one GPU per rank; "
+                 f"run with --gpus <= {max(ndev, 1)}, or rehearse {world} ranks on the GPUs present with T3_BENCH_BACKEND=gloo")
+
+
 def spawn_ranks(args):
     """--gpus N without a launcher: start the N ranks as children (nothing in this process has touched the GPU) and relay rank 0."""
+    check_gpu_count(args.gpus)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
@@ -105,9 +142,11 @@ def build_requests(E, args, rank):
     from chatterbox_vllm2_amd.prompt import assemble_prompt_ids
     tok = json.load(open(os.path.join(ROOT, "tests", "golden", "tokenizer.json")))
     p_en, p_es = assemble_prompt_ids(tok["en_mtl_ids"]), assemble_prompt_ids(tok["es_mtl_ids"])
+    p_c2 = assemble_prompt_ids(tok["en_english_ids"])
+    assert (len(p_en), len(p_es), len(p_c2)) == (T_EN, T_ES, T_C2)
     reqs = []
     for i in range(args.batch):
-        prompt = p_en if i < args.batch // 2 else p_es
+        prompt = p_c2 if args.workload == "c2" else (p_en if i < args.batch // 2 else p_es)
         uid = rank * args.batch + i                       # global utterance id: shards are disjoint
         sp = E.make_sampling(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=0, uid=uid,
                              max_tokens=args.max_model_len - len(prompt), ignore_eos=True)
@@ -130,6 +169,21 @@ def build_c4_requests(E, args, rank, world):
         sp = E.make_sampling(max_tokens=r["max_tokens"], ignore_eos=True, uid=g, **c4["sampling"])
         reqs.append((g, assemble_prompt_ids(r["text_ids"]), sp))
     return reqs, n, c4
+
+
+def step_percentiles(ms, prefix="step_ms"):
+    """p50 / p90 / p99 of the timed steps' own durations (SURVEY.md 8(d) "step-latency histogram")."""
+    import numpy as np
+    if len(ms) == 0:
+        return {}
+    a = np.asarray(ms, dtype=np.float64)
+    return {f"{prefix}_p50": round(float(np.percentile(a, 50)), 4), f"{prefix}_p90": round(float(np.percentile(a, 90)), 4),
+            f"{prefix}_p99": round(float(np.percentile(a, 99)), 4), f"{prefix}_max": round(float(a.max()), 4)}
+
+
+def file_sha16(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
 def rtf_stats(eng, reqs, n_tokens):
@@ -172,12 +226,13 @@ def run_pass(eng, reqs, cond, ff, warmup, steps, sync, profile=False, only=None)
     assert done == steps, f"only {done} of {steps} steps ran (fast-forward + warmup + steps must stay below max_model_len - longest prompt)"
     st = eng.stats()
     assert st.decode_steps == steps and st.tokens_generated == steps * len(reqs)
+    step_ms, _ = eng.step_times(steps)
     kern = {k: eng.kernel_ms(k) for k in __import__("chatterbox_vllm2_amd.engine", fromlist=["x"]).KERNEL_CLASSES} if profile else {}
     # drain: finish the utterances quickly (not timed) so the engine is reusable
     eng.run_until_done()
     for rid, _, _ in reqs:
         eng.release(rid)
-    return dict(dt=dt, prefill_s=prefill_s, prefill_steps=n_pref, stats=st, kern=kern)
+    return dict(dt=dt, prefill_s=prefill_s, prefill_steps=n_pref, stats=st, kern=kern, step_ms=step_ms)
 
 
 def run_e2e(eng, reqs, cond):
@@ -222,7 +277,8 @@ def run_c4(eng, reqs, cond, warmup, steps, sync):
     if done != steps:
         sys.exit(f"only {done} of {steps} engine steps were left after {warmup} warmup steps: lower --steps for this request stream")
     tokens_window = int(st.tokens_generated)
-    window = dict(dt=dt, tokens=tokens_window, decode_only_steps=int(st.decode_steps), prefill_rows=int(st.prefill_rows), decode_rows=int(st.decode_rows),
+    step_ms, step_rows = eng.step_times(steps)
+    window = dict(step_ms=step_ms, step_rows=step_rows, dt=dt, tokens=tokens_window, decode_only_steps=int(st.decode_steps), prefill_rows=int(st.prefill_rows), decode_rows=int(st.decode_rows),
                   ms_decode_only=st.gpu_ms_decode / max(1, st.decode_steps), algo_bytes_decode=st.algo_bytes_decode, gpu_ms_decode=st.gpu_ms_decode,
                   mean_ctx=st.sum_ctx_decode / max(1, st.decode_rows))
     eng.run_until_done()
@@ -246,8 +302,9 @@ def cpu_baseline(weights, args):
     from oracle import oracle as O
     ncores = int(os.environ.get("T3_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))   # the box grants a 16-core share
     O.set_threads(ncores)
-    B, ctx, steps = min(args.batch, 32), 500, 5          # ~13 s of CPU work on the box's 16-core share
-    m = O.OracleModel(args.layers, 2454, max_pos=ctx + steps + 2, n_streams=2 * B).load(weights)
+    B, ctx = min(args.batch, 32), (500 if args.workload != "c2" else 250)
+    steps = 5 if B > 1 else 40                          # ~13 s of CPU work on the box's 16-core share (B = 1: ~0.3 s per step)
+    m = O.OracleModel(args.layers, args.vocab, max_pos=ctx + steps + 2, n_streams=2 * B).load(weights)
     m.decode_steps_timing(1, ctx, 1)                     # touch the weights once
     t0 = time.perf_counter()
     m.decode_steps_timing(B, ctx, steps)
@@ -269,16 +326,26 @@ def dominant_kernel_roofline(prof, dom_only, args):
     else:
         algo = wbytes.get(dom, 0)
     ms = dom_only["kern"][dom][0]                  # events around this class only
-    # HBM bytes per launch from the PMC pass recorded in profiles/traffic.json (FETCH_SIZE, gfx950 x2 correction):
-    # the measured bytes/algorithmic-bytes ratio of that pass applied to this run's algorithmic bytes per launch
-    traffic = None
+    # HBM bytes per launch: NOT measured by this run (PMC counters need rocprofv3 around the process).  profiles/traffic.json holds the
+    # bytes-fetched / algorithmic-bytes ratio of the committed FETCH_SIZE pass (gfx950 x2 correction) together with the sha256 of the
+    # kernel source it was collected on; the ratio is applied to this run's algorithmic bytes ONLY while that source is unchanged,
+    # otherwise traffic is null (a stale ratio is not a measurement of this kernel).
+    traffic, traffic_source = None, "none: profiles/traffic.json has no entry for this kernel class"
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
-        rec = json.load(open(tf)).get(dom)
+        tj = json.load(open(tf))
+        rec = tj.get(dom)
         if rec and "ratio" in rec:
-            traffic = round(rec["ratio"] * algo)
+            src = os.path.join(ROOT, "chatterbox-vllm2_amd", "csrc", rec.get("source_file", "t3_attention.hip" if dom == "attention" else "t3_gemm.hip"))
+            now, then = file_sha16(src), rec.get("source_sha16")
+            if then == now:
+                traffic = round(rec["ratio"] * algo)
+                traffic_source = (f"ratio {rec['ratio']:.4f} of the committed rocprofv3 --pmc FETCH_SIZE pass {rec.get('pass', 'profiles/traffic.json')} "
+                                  f"(x2 gfx950 correction) applied to this run's algorithmic bytes; kernel source unchanged since (sha256 {now})")
+            else:
+                traffic_source = f"null: {os.path.basename(src)} changed since the committed FETCH_SIZE pass (sha256 {then} -> {now}); re-run tools/run_profiles.sh"
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "algo_bytes_per_launch": round(algo), "avg_launch_ms": round(ms, 5), "launches": kern[dom][1],
             "timing": "HIP events on the engine's stream, as the start / stop events of every launch of this kernel class (hipExtLaunchKernelGGL: "
                       "the dispatch's begin / end) in a pass of the same steps; the rocprofv3 average of the same kernel is in profiles/README.md"}
@@ -287,7 +354,7 @@ def dominant_kernel_roofline(prof, dom_only, args):
 
 def main():
     args = parse()
-    ff, first, last = plan_window(args) if args.workload == "c3" else (0, 0, 0)
+    ff, first, last = plan_window(args) if args.workload != "c4" else (0, 0, 0)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
     import torch
@@ -298,6 +365,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    check_gpu_count(world)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the T3 engine has no CPU path")
     # T3_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box); default RCCL.
@@ -334,11 +402,11 @@ def main():
     from chatterbox_vllm2_amd import engine as E
     from chatterbox_vllm2_amd.weights import synthetic_cond_emb, synthetic_tensors
 
-    weights = list(synthetic_tensors(args.layers, 2454, 1234))
+    weights = list(synthetic_tensors(args.layers, args.vocab, 1234))
     cond = synthetic_cond_emb(1)
     share = max(1, (world if backend != "nccl" else 1))                     # ranks sharing one GPU in a gloo rehearsal
-    eng = E.T3Engine(n_layers=args.layers, text_vocab=2454, max_model_len=args.max_model_len, max_seqs=args.batch,
-                     device_id=dev, gpu_memory_utilization=(0.5 if args.workload == "c3" else 0.6) / share, max_batched_rows=8192,
+    eng = E.T3Engine(n_layers=args.layers, text_vocab=args.vocab, max_model_len=args.max_model_len, max_seqs=args.batch,
+                     device_id=dev, gpu_memory_utilization=(0.6 if args.workload == "c4" else 0.5) / share, max_batched_rows=8192,
                      enforce_eager=bool(int(os.environ.get("T3_EAGER", "0"))))
     eng.load_tensors(weights); eng.finalize()
     common = {"metric": "speech-tokens/sec/GPU (T3 decode, batch=32) + p50 RTF", "unit": "speech-tokens/s", "n_gpus": world, "steps": args.steps,
@@ -366,6 +434,10 @@ def main():
                                    "weights": "seeded synthetic N(0,0.02^2), seed 1234"},
                         "tokens_per_s_per_gpu": round(tokens / dt / world, 2),
                         "rtf_p50": e2e["rtf_p50"], "rtf_p90": e2e["rtf_p90"],
+                        **step_percentiles(window["step_ms"]),
+                        "step_ms_by_kind_rank0": {"decode_only": dict(n=int((window["step_rows"] > 0).sum()), **step_percentiles(window["step_ms"][window["step_rows"] > 0], "ms")),
+                                                  "with_prefill_rows": dict(n=int((window["step_rows"] < 0).sum()), mean_rows=round(float(-window["step_rows"][window["step_rows"] < 0].mean()), 1) if (window["step_rows"] < 0).any() else 0,
+                                                                            **step_percentiles(window["step_ms"][window["step_rows"] < 0], "ms"))},
                         "window_rank0": {"decode_only_steps": window["decode_only_steps"], "prefill_rows": window["prefill_rows"], "decode_rows": window["decode_rows"],
                                          "ms_per_decode_only_step": round(window["ms_decode_only"], 4), "mean_ctx_decode": round(window["mean_ctx"], 1),
                                          "step_hbm_frac_decode_only": round(window["algo_bytes_decode"] / max(1e-9, window["gpu_ms_decode"] * 1e-3) / 8e12, 4)},
@@ -398,7 +470,7 @@ def main():
         total_tokens = world * args.batch * args.steps
         value = total_tokens / dt
         bytes_step = st.algo_bytes_decode / st.decode_steps
-        mean_T = (T_EN * (args.batch // 2) + T_ES * (args.batch - args.batch // 2)) / args.batch
+        mean_T = T_C2 if args.workload == "c2" else (T_EN * (args.batch // 2) + T_ES * (args.batch - args.batch // 2)) / args.batch
         out = dict(common)
         out.update({
             "value": round(value, 2), "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -411,6 +483,7 @@ def main():
             # in the timed window every utterance emits one token per step: its RTF there is the step time x 25.  The per-request figure
             # over whole utterances (prefill included) is e2e.rtf_p50 / rtf_p90.
             "rtf_p50": round((dt / args.steps) * S3_TOKEN_RATE, 5),
+            **step_percentiles(res["step_ms"]),
             "prefill_ms": round(res["prefill_s"] * 1e3, 2), "prefill_steps": res["prefill_steps"],
             "mean_ctx": round(st.sum_ctx_decode / st.decode_rows, 1),
             "step_roofline": {"bound": "hbm", "algo_bytes_per_step": round(bytes_step), "achieved": round(bytes_step / (dt / args.steps) / 1e9, 1),

@@ -131,6 +131,9 @@ struct T3Engine {
     bool run_ahead = true;     // t3_run_steps / t3_run_until_done enqueue step N+1 before reading step N's tokens
     int64_t graph_captures = 0; double graph_capture_ms = 0;      // T3_GRAPH_STATS=1 prints them at destroy
     std::chrono::steady_clock::time_point t_last_complete{};
+    std::vector<float> step_ms_ring = std::vector<float>(16384, 0.0f);   // t3_step_times: duration of the most recent steps (as accounted in gpu_ms_total)
+    std::vector<int32_t> step_rows_ring = std::vector<int32_t>(16384, 0);
+    uint64_t steps_recorded = 0;
     float* d_cond = nullptr;
     uint16_t* d_counts = nullptr;
     T3Sampling* d_sp = nullptr;
@@ -751,6 +754,7 @@ static int complete_step(T3Engine* e, T3Engine::Step& st, T3StepResult* res) {
     const double ms = std::chrono::duration<double, std::milli>(now - t0).count();
     const bool decode_only = (st.n_prefill_rows == 0);
     e->st.steps++; e->st.gpu_ms_total += ms; e->st.prefill_rows += st.n_prefill_rows; e->st.decode_rows += st.decode_rows;
+    e->step_ms_ring[e->steps_recorded % e->step_ms_ring.size()] = (float)ms; e->step_rows_ring[e->steps_recorded % e->step_ms_ring.size()] = st.n_prefill_rows > 0 ? -st.M_all : st.M_all; ++e->steps_recorded;
     if (decode_only) {
         e->st.decode_steps++; e->st.gpu_ms_decode += ms; e->st.sum_ctx_decode += st.sum_ctx;
         // W + KV read + KV write + embedding rows, scaled to n_layers
@@ -983,10 +987,21 @@ extern "C" int t3_debug_logits(T3Handle e, int64_t req_id, float* out) {
     return T3_OK;
 }
 
+extern "C" int t3_step_times(T3Handle e, float* ms, int32_t* rows, int32_t cap) {
+    if (!e || cap < 0 || (cap > 0 && !ms)) return T3_E_INVALID;
+    const uint64_t have = std::min<uint64_t>(e->steps_recorded, e->step_ms_ring.size());
+    const int n = (int)std::min<uint64_t>(have, (uint64_t)cap);
+    for (int i = 0; i < n; ++i) {
+        const uint64_t k = (e->steps_recorded - n + i) % e->step_ms_ring.size();
+        ms[i] = e->step_ms_ring[k]; if (rows) rows[i] = e->step_rows_ring[k];
+    }
+    return n;
+}
 extern "C" int t3_stats(T3Handle e, T3Stats* out) { if (!e || !out) return T3_E_INVALID; *out = e->st; return T3_OK; }
 extern "C" int t3_reset_stats(T3Handle e) {
     if (!e) return T3_E_INVALID;
     const int64_t bt = e->st.kv_blocks_total, bf = e->st.kv_blocks_free, wb = e->st.weight_bytes, fd = e->st.finished_dropped;
+    e->steps_recorded = 0;
     e->st = T3Stats{}; e->st.kv_blocks_total = bt; e->st.kv_blocks_free = bf; e->st.weight_bytes = wb; e->st.finished_dropped = fd;
     for (int k = 0; k < K_COUNT; ++k) { e->k_ms[k] = 0; e->k_n[k] = 0; }
     return T3_OK;

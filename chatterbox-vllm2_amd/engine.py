@@ -61,7 +61,7 @@ class T3Stats(ct.Structure):
 ABI_SYMBOLS = [
     "t3_create", "t3_destroy", "t3_last_error", "t3_load_tensor", "t3_finalize_weights", "t3_add_request",
     "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_get_timing", "t3_release_request", "t3_abort_request", "t3_handoff_tokens", "t3_reserve_handoff", "t3_pop_finished", "t3_debug_embeddings", "t3k_handoff",
-    "t3_clean_tokens", "t3_debug_logits", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_set_profile_kernel", "t3_kernel_ms",
+    "t3_clean_tokens", "t3_debug_logits", "t3_step_times", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_set_profile_kernel", "t3_kernel_ms",
     "t3k_gemm", "t3k_norm_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_decode_attention", "t3k_sample", "t3k_sample_support", "t3k_expf",
     "t3_cond_create", "t3_cond_destroy", "t3_cond_last_error", "t3_cond_load_tensor", "t3_cond_encode", "t3_cond_emotion_row",
     "t3k_ce_layernorm", "t3k_ce_linear", "t3k_ce_attention", "t3k_set_prefill_rows", "t3k_set_prefill_wide_rows",
@@ -113,6 +113,7 @@ def load_library():
     L.t3_clean_tokens.argtypes = [vp, i32, i32, i32, vp, ct.POINTER(i32)]
     L.t3_debug_logits.argtypes = [vp, i64, vp]
     L.t3_stats.argtypes = [vp, ct.POINTER(T3Stats)]
+    L.t3_step_times.argtypes = [vp, vp, vp, i32]
     L.t3_reset_stats.argtypes = [vp]
     L.t3_set_profile.argtypes = [vp, i32]
     L.t3_set_profile_kernel.argtypes = [vp, ct.c_char_p]
@@ -316,6 +317,14 @@ class T3Engine:
 
     def reset_stats(self):
         self._chk(self.lib.t3_reset_stats(self.h))
+
+    def step_times(self, cap: int = 16384):
+        """(ms [n] float32, rows [n] int32) of the most recent steps since reset_stats, oldest first; rows < 0: the step carried prefill rows"""
+        ms = np.zeros(max(1, cap), dtype=np.float32); rows = np.zeros(max(1, cap), dtype=np.int32)
+        n = int(self.lib.t3_step_times(self.h, ct.c_void_p(ms.ctypes.data), ct.c_void_p(rows.ctypes.data), int(cap)))
+        if n < 0:
+            self._chk(n)
+        return ms[:n], rows[:n]
 
     def set_profile(self, on: bool, only: Optional[str] = None):
         """HIP events around every kernel launch of decode-only steps; only = one kernel class (the rest runs undisturbed)."""

@@ -181,6 +181,11 @@ int t3_debug_logits(T3Handle h, int64_t req_id, float* out_8194);
  * half, 2 * slot + 1 for the unconditional half of the reference's [N, 2048] layout) and position; needs cfg.debug_logits = 1.
  * On entry *n = capacity in rows (out_bf16 / row_stream / row_pos may be NULL); on exit *n = rows of the step. */
 int t3_debug_embeddings(T3Handle h, void* out_bf16, int32_t* row_stream, int32_t* row_pos, int32_t* n);
+/* Durations (ms) of the most recent steps since t3_reset_stats, oldest first (at most cap, at most the last 16 384): the time each step
+ * had the GPU to itself, i.e. from the completion of the step before it (or its own enqueue, if later) to its own completion as the host
+ * sees it (the same clock gpu_ms_total sums).  rows (nullable): the step's row count, negative when it carried prefill rows.
+ * Returns the number written.  For the p50 / p90 / p99 step latency SURVEY.md 8(d) asks for. */
+int t3_step_times(T3Handle h, float* ms, int32_t* rows, int32_t cap);
 int t3_stats(T3Handle h, T3Stats* out);
 int t3_reset_stats(T3Handle h);
 /* Average duration (ms) per launch of each kernel class over decode-only steps since the last reset,

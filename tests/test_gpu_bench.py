@@ -53,3 +53,13 @@ def test_bench_c4_two_ranks():
     e = out["e2e"]
     assert e["requests"] == out["config"]["requests_rank0"] and 0 < e["rtf_p50"] <= e["rtf_p90"] and e["rtf_incl_queue_p90"] >= e["rtf_p90"]
     assert e["value_all_ranks"] > e["value"] * 1.2           # two ranks' tokens over the slower rank's wall
+
+
+def test_bench_c2_line_and_step_percentiles():
+    """`--workload c2` = BASELINE.json configs[1] (English vocabulary 704, the T = 108 prompt, B = 1, max_model_len 400): the line a reader
+    compares with the reference's only published number; every line carries the step-latency percentiles SURVEY.md 8(d) asks for."""
+    out = _bench(["--workload", "c2", "--steps", "30", "--warmup", "5", "--layers", "2", "--no-cpu-baseline"], {})
+    assert CONTRACT_KEYS <= set(out) and out["config"]["workload"].startswith("custom")       # 2 layers: not the BASELINE config, and labelled so
+    assert out["config"]["batch_per_gpu"] == 1 and out["config"]["max_model_len"] == 400 and "T=108" in out["config"]["workload"] and "vocab 704" in out["config"]["workload"]
+    assert 0 < out["step_ms_p50"] <= out["step_ms_p90"] <= out["step_ms_p99"] <= out["step_ms_max"]
+    assert out["e2e"]["tokens"] == 292 and out["roofline"]["frac"] > 0 and "traffic_source" in out["roofline"]
