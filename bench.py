@@ -320,7 +320,8 @@ def dominant_kernel_roofline(prof, dom_only, args):
     tot = {k: v[0] * v[1] for k, v in kern.items()}
     dom = max(tot, key=tot.get)
     wbytes = {"gemm_qkv": 3072 * 1024 * 2, "gemm_o": 1024 * 1024 * 2, "gemm_gateup": 8192 * 1024 * 2, "gemm_down": 4096 * 1024 * 2,
-              "gemm_head": 8194 * 1024 * 2}
+              "gemm_head": 8194 * 1024 * 2,
+              "sampler": args.batch * 3 * 8208 * 2, "embed": args.batch * 2 * 3 * 2048}      # per launch: two logit rows + the counts per utterance; table rows in, one row out
     if dom == "attention":      # KV read of one layer: sum over the 2B rows of ctx * 4096 B (SURVEY 8d per-unit figure / 30 layers)
         algo = pst.sum_ctx_decode / pst.decode_steps * KV_BYTES_TOK_STREAM_LAYER
     else:

@@ -55,6 +55,7 @@ struct Request {
     // index of the newest one in its group's sampler output array, and whether a row of an already finished
     // request is still in flight (its slot is released when that step completes)
     int n_sched = 0, last_idx = -1;
+    int n_seen = 0;                   // sampled results read back (kept or, once finished, dropped): == n_sched when nothing of it is in flight
     bool zombie = false;
     int32_t* d_out = nullptr;         // finished: the utterance's speech-space ids on the device (f4 hand-off), from the engine's buffer pool
     double t_add = 0, t_admit = 0, t_first = 0, t_finish = 0;     // seconds since the engine was created (t3_get_timing)
@@ -100,18 +101,23 @@ struct T3Engine {
     // utterance groups: each group owns a stream, activation buffers, step metadata and captured graphs (measured: kernels of two
     // streams do not overlap usefully on this part, profiles/NOTES.md; one group is the default)
     struct Meta { int* sel_rows; int4* sel; int* rows; int* out_tok; };   // sel arrays first, then the row records (one contiguous upload)
+    // Decode steps per graph replay ("burst").  A replay's hand-over costs the GPU ~13 us of idle time against ~1.5 us between two kernels
+    // of one graph (profiles/r03_e_step_timeline.json), so while nothing can change the row set -- no request waits for admission, none is in
+    // prefill, none reaches its length limit -- BURST_MAX consecutive decode steps are captured and replayed as ONE graph: step j + 1 reads
+    // the token step j drew straight from the sampler's device array (EMB_SPEECH_PREV), its metadata from its own pinned buffer of the ring.
+    static constexpr int BURST_MAX = 4, NBUF = 2 * BURST_MAX;
     struct Group {
         hipStream_t stream = nullptr;
         uint16_t *h = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *act = nullptr, *logits = nullptr;
         float* rstd = nullptr;     // row statistic of the prefill-sized NORM GEMMs
-        char *h_meta[2] = {nullptr, nullptr}, *d_meta = nullptr;     // host staging is double-buffered: step N+1 is built while N runs
+        char *h_meta[NBUF] = {}, *d_meta = nullptr;     // host staging ring: the steps of the burst that runs and of the one built ahead of it
         size_t meta_bytes = 0, meta_rows_off = 0;
-        Meta hm[2]{}, dm{};
-        int* h_out_tok[2] = {nullptr, nullptr};
+        Meta hm[NBUF]{}, dm{};
+        int* h_out_tok[NBUF] = {};
         uint64_t waited_admit_seq = 0;     // the admission this group's stream has been ordered behind
-        hipEvent_t ev_done[2] = {nullptr, nullptr};
+        hipEvent_t ev_done[NBUF] = {};
         int rcap = 0;              // row budget per step
-        std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;   // (M, n_sel, staging buffer) -> captured decode step
+        std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;   // (M, n_sel, first staging buffer, steps) -> captured decode step(s)
     };
     // One enqueued step: what the scheduler put on each group's stream, kept until its tokens are back.
     struct StepRec {
@@ -129,6 +135,7 @@ struct T3Engine {
     std::vector<Group> groups;
     unsigned step_seq = 0;
     bool run_ahead = true;     // t3_run_steps / t3_run_until_done enqueue step N+1 before reading step N's tokens
+    int burst = BURST_MAX;     // T3_STEPS_PER_GRAPH: decode steps per graph replay in the run loops (1 = one step per replay)
     int64_t graph_captures = 0; double graph_capture_ms = 0;      // T3_GRAPH_STATS=1 prints them at destroy
     std::chrono::steady_clock::time_point t_last_complete{};
     std::vector<float> step_ms_ring = std::vector<float>(16384, 0.0f);   // t3_step_times: duration of the most recent steps (as accounted in gpu_ms_total)
@@ -211,6 +218,7 @@ extern "C" int t3_create(const T3EngineConfig* cfg, T3Handle* out) {
         if (const char* ev = getenv("T3_ZERO_COPY")) e->zero_copy = atoi(ev) != 0;
         if (const char* ev = getenv("T3_PREFETCH_DOWN_LINES")) e->prefetch_down_lines = atoi(ev);
         if (const char* ev = getenv("T3_RUN_AHEAD")) e->run_ahead = atoi(ev) != 0;
+        if (const char* ev = getenv("T3_STEPS_PER_GRAPH")) e->burst = std::max(1, std::min(atoi(ev), (int)T3Engine::BURST_MAX));
     }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail_create(T3_E_DEVICE, "hipStreamCreate failed"); }
     hipEventCreate(&e->ev0); hipEventCreate(&e->ev1); hipEventCreateWithFlags(&e->ev_admit, hipEventDisableTiming);
@@ -236,7 +244,7 @@ extern "C" int t3_destroy(T3Handle e) {
         for (auto& kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
         free_dev(g.h); free_dev(g.qkv); free_dev(g.qrot); free_dev(g.att); free_dev(g.act); free_dev(g.logits); free_dev(g.rstd);
         free_dev(g.d_meta); free_dev(g.dm.out_tok);
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < T3Engine::NBUF; ++b) {
             if (g.h_meta[b]) (void)hipHostFree(g.h_meta[b]);
             if (g.h_out_tok[b]) (void)hipHostFree(g.h_out_tok[b]);
             if (g.ev_done[b]) (void)hipEventDestroy(g.ev_done[b]);
@@ -409,7 +417,7 @@ extern "C" int t3_finalize_weights(T3Handle e) {
         auto fill = [&](T3Engine::Meta& m, char* base) {
             m.sel_rows = (int*)(base + o_selr); m.sel = (int4*)(base + o_sel); m.rows = (int*)(base + o_rows); m.out_tok = nullptr;
         };
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < T3Engine::NBUF; ++b) {
             HIP_TRY(hipHostMalloc((void**)&g.h_meta[b], g.meta_bytes, hipHostMallocDefault));
             memset(g.h_meta[b], 0, g.meta_bytes);
             fill(g.hm[b], g.h_meta[b]);
@@ -623,14 +631,15 @@ static int launch_step(T3Engine* e, T3Engine::Group& g, const T3Engine::StepRec&
     }
     return launch_sample_phase(e, g, sr, buf, s);
 }
-// Schedule one step and put it on the streams.  Does not wait for anything: a decode row whose input token is still
-// being sampled by the previous step refers to it by its index in the sampler's output array (EMB_SPEECH_PREV).
-static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
+// Schedule one step into its staging buffer (nothing is launched).  Does not wait for anything: a decode row whose input token is
+// still being sampled by the previous step refers to it by its index in the sampler's output array (EMB_SPEECH_PREV).
+// may_admit = false: a later step of a burst -- the row set must stay what the burst's first step found.
+static int build_step(T3Engine* e, T3Engine::Step& st, bool may_admit) {
     int rc;
-    if ((rc = admit(e))) return rc;
+    if (may_admit && (rc = admit(e))) return rc;
     st = T3Engine::Step{};
     st.g.resize(e->n_groups);
-    st.buf = (int)(e->step_seq++ & 1u);
+    st.buf = (int)(e->step_seq++ % T3Engine::NBUF);
     const int buf = st.buf;
     auto add_row = [&](int gi, int stream, int pos, int kind, int a, int b) {
         T3Engine::StepRec& sr = st.g[gi];
@@ -684,8 +693,32 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
     }
     for (auto& sr : st.g) { st.M_all += sr.M; st.n_prefill_rows += sr.n_prefill_rows; st.n_sampled += sr.n_sel; st.decode_rows += sr.decode_rows; st.sum_ctx += sr.sum_ctx; }
     st.t_begin = std::chrono::steady_clock::now();
-    if (st.M_all == 0) return T3_OK;
+    return T3_OK;
+}
 
+// Can the step after `st` (a decode-only step) be built now and run with exactly st's rows?  Nothing waits in prefill, every decoding
+// request has a step left, and nothing changes the row set in between (an admission needs a finish, and a finish needs a token the host
+// has not seen: a stop id inside a burst is met when the burst completes -- the utterance's later rows of the burst are dropped, as the
+// one row of the run-ahead step always was).
+static bool burst_can_continue(T3Engine* e, const T3Engine::Step& st) {
+    if (st.n_prefill_rows != 0 || st.M_all == 0) return false;
+    int decoding = 0;
+    for (int64_t id : e->running) {
+        const Request& r = e->reqs[id];
+        if (r.state == PREFILL) return false;
+        if (r.state != DECODE) continue;
+        if (r.n_sched >= r.limit) return false;      // its last token is in flight: the next step has fewer rows
+        ++decoding;
+    }
+    return 2 * decoding == st.M_all;
+}
+
+// Put `n` built steps (n > 1: a burst of decode-only steps with one row set) on the streams: eager, one graph replay per step, or ONE
+// graph replay for the burst.  The completion event is recorded behind the last step only (its ev_done slot).
+static int launch_steps(T3Engine* e, T3Engine::Step* steps, int n) {
+    T3Engine::Step& st = steps[0];
+    if (st.M_all == 0) return T3_OK;
+    const int buf = st.buf, buf_last = steps[n - 1].buf;
     const bool graphs_ok = !e->cfg.enforce_eager && !e->profile && st.n_prefill_rows == 0;
     for (int gi = 0; gi < e->n_groups; ++gi) {
         T3Engine::Group& g = e->groups[gi];
@@ -699,19 +732,20 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
             for (int r = 0; r < sr.M; ++r) { const int* rec = g.hm[buf].rows + (size_t)r * e->row_stride; e->dbg_emb_rec[2 * r] = rec[0]; e->dbg_emb_rec[2 * r + 1] = rec[1]; }
         }
         if (graphs_ok) {
-            const auto key = std::make_tuple(sr.M, sr.n_sel, e->zero_copy ? buf : 0);      // zero-copy: the pinned buffers of `buf` are kernel arguments
+            const auto key = std::make_tuple(sr.M, sr.n_sel, e->zero_copy ? buf : 0, n);      // zero-copy: the pinned buffers of `buf` ... are kernel arguments
             auto it = g.graphs.find(key);
             if (it == g.graphs.end()) {
                 hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
                 const auto tc0 = std::chrono::steady_clock::now();
                 HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                const int lrc = launch_step(e, g, sr, buf, s);
+                int lrc = T3_OK;
+                for (int j = 0; j < n && !lrc; ++j) lrc = launch_step(e, g, steps[j].g[gi], steps[j].buf, s);
                 const hipError_t ce = hipStreamEndCapture(s, &graph);
                 if (lrc) return lrc;
                 HIP_TRY(ce);
                 HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
                 (void)hipGraphDestroy(graph);
-                if (g.graphs.size() > 64) {          // a replay of one of them may still be running (run-ahead): drain first
+                if (g.graphs.size() > 192) {         // a replay of one of them may still be running (run-ahead): drain first
                     HIP_TRY(hipStreamSynchronize(s));
                     for (auto& kv : g.graphs) (void)hipGraphExecDestroy(kv.second);
                     g.graphs.clear();
@@ -721,13 +755,26 @@ static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
             }
             HIP_TRY(hipGraphLaunch(it->second, s));
         } else {
-            int lrc;
-            if ((lrc = launch_step(e, g, sr, buf, s))) return lrc;
+            for (int j = 0; j < n; ++j) { const int lrc = launch_step(e, g, steps[j].g[gi], steps[j].buf, s); if (lrc) return lrc; }
         }
         if (sr.n_sel > 0 && !e->zero_copy) HIP_TRY(hipMemcpyAsync(g.h_out_tok[buf], g.dm.out_tok, (size_t)sr.n_sel * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(g.ev_done[buf], s));
+        HIP_TRY(hipEventRecord(g.ev_done[buf_last], s));
     }
     return T3_OK;
+}
+static bool bursts_enabled(const T3Engine* e) { return e->burst > 1 && e->zero_copy && !e->cfg.enforce_eager && !e->profile && !e->cfg.debug_logits; }
+// Every item (a step or a burst) starts on a window boundary of the staging ring: its graph is keyed by its first buffer, so windows keep
+// the number of captured variants per shape at NBUF / burst instead of NBUF, and two items in flight never share a buffer.
+static void begin_item(T3Engine* e) {
+    const unsigned B = bursts_enabled(e) ? (unsigned)e->burst : 1u;
+    if (e->step_seq % B) e->step_seq += B - e->step_seq % B;
+}
+// one step: schedule + launch (t3_step)
+static int enqueue_step(T3Engine* e, T3Engine::Step& st) {
+    int rc;
+    begin_item(e);
+    if ((rc = build_step(e, st, true))) return rc;
+    return launch_steps(e, &st, 1);
 }
 
 // n more per-utterance device id buffers for the hand-off pool, carved from one allocation
@@ -743,15 +790,20 @@ static int grow_out_pool(T3Engine* e, int n) {
 }
 
 // Wait for an enqueued step, account for it and hand its tokens to the requests.
-static int complete_step(T3Engine* e, T3Engine::Step& st, T3StepResult* res) {
+// burst_ms < 0: wait for the step's own completion event and clock it.  burst_ms >= 0: the step belongs to a burst whose event (recorded
+// behind its last step) the caller has waited for; burst_ms = the burst's time / its steps (the steps of one replay cannot be clocked apart).
+static int complete_step(T3Engine* e, T3Engine::Step& st, T3StepResult* res, double burst_ms = -1.0) {
     res->n_rows = st.M_all; res->n_prefill_rows = st.n_prefill_rows; res->n_sampled = st.n_sampled;
     if (st.M_all == 0) { res->n_running = (int)e->running.size(); res->n_waiting = (int)e->waiting.size(); return T3_OK; }
-    for (int gi = 0; gi < e->n_groups; ++gi) if (st.g[gi].M) HIP_TRY(hipEventSynchronize(e->groups[gi].ev_done[st.buf]));
-    const auto now = std::chrono::steady_clock::now();
-    // with a step running ahead, this step had the GPU to itself only since the previous one completed
-    const auto t0 = std::max(st.t_begin, e->t_last_complete);
-    e->t_last_complete = now;
-    const double ms = std::chrono::duration<double, std::milli>(now - t0).count();
+    double ms = burst_ms;
+    if (burst_ms < 0) {
+        for (int gi = 0; gi < e->n_groups; ++gi) if (st.g[gi].M) HIP_TRY(hipEventSynchronize(e->groups[gi].ev_done[st.buf]));
+        const auto now = std::chrono::steady_clock::now();
+        // with a step running ahead, this step had the GPU to itself only since the previous one completed
+        const auto t0 = std::max(st.t_begin, e->t_last_complete);
+        e->t_last_complete = now;
+        ms = std::chrono::duration<double, std::milli>(now - t0).count();
+    }
     const bool decode_only = (st.n_prefill_rows == 0);
     e->st.steps++; e->st.gpu_ms_total += ms; e->st.prefill_rows += st.n_prefill_rows; e->st.decode_rows += st.decode_rows;
     e->step_ms_ring[e->steps_recorded % e->step_ms_ring.size()] = (float)ms; e->step_rows_ring[e->steps_recorded % e->step_ms_ring.size()] = st.n_prefill_rows > 0 ? -st.M_all : st.M_all; ++e->steps_recorded;
@@ -775,8 +827,9 @@ static int complete_step(T3Engine* e, T3Engine::Step& st, T3StepResult* res) {
         const int* toks = e->groups[gi].h_out_tok[st.buf];
         for (int i = 0; i < sr.n_sel; ++i) {
             Request& r = *sr.sampled[i];
-            if (r.state == FINISHED) {       // row scheduled before its stop token was seen: drop the result, free the slot now
-                if (r.zombie) { r.zombie = false; release_slot(e, r); }
+            ++r.n_seen;
+            if (r.state == FINISHED) {       // row scheduled before its stop token was seen: drop the result; the slot is free once its last row in flight is back
+                if (r.zombie && r.n_seen >= r.n_sched) { r.zombie = false; release_slot(e, r); }
                 continue;
             }
             const int tok = toks[i];
@@ -831,36 +884,67 @@ extern "C" int t3_step(T3Handle e, T3StepResult* res) {
     return complete_step(e, st, res);
 }
 
-// The step loop of t3_run_steps / t3_run_until_done.  With run-ahead, step N+1 is scheduled and enqueued before the
-// host waits for step N, so the device never idles across the token read-back and the scheduler.  An utterance whose
-// stop token turns up in step N has one wasted row pair in step N+1; its token stream is unaffected.
+// The step loop of t3_run_steps / t3_run_until_done.  With run-ahead, the next item (a step, or a burst of decode steps replayed as one
+// graph) is scheduled and enqueued before the host waits for the current one, so the device never idles across the token read-back
+// and the scheduler.  An utterance whose stop token turns up in step N has wasted row pairs in the steps already enqueued behind N (one
+// with single steps, up to 2 * burst - 1 with bursts); its token stream is unaffected.
+namespace {
+struct Item { T3Engine::Step steps[T3Engine::BURST_MAX]; int n = 0; };
+}
+// schedule + launch the next item: up to `room` steps (>= 1); a burst only where the row set provably stays the same
+static int enqueue_item(T3Engine* e, Item& it, int64_t room) {
+    int rc;
+    it.n = 0;
+    const bool burst_ok = bursts_enabled(e);
+    begin_item(e);
+    if ((rc = build_step(e, it.steps[0], true))) return rc;
+    it.n = 1;
+    if (it.steps[0].M_all == 0) return T3_OK;
+    while (burst_ok && it.n < e->burst && it.n < room && burst_can_continue(e, it.steps[it.n - 1])) {
+        if ((rc = build_step(e, it.steps[it.n], false))) return rc;
+        ++it.n;
+    }
+    return launch_steps(e, it.steps, it.n);
+}
+static int complete_item(T3Engine* e, Item& it, T3StepResult* r) {
+    if (it.n == 1) { memset(r, 0, sizeof(*r)); return complete_step(e, it.steps[0], r); }
+    T3Engine::Step& last = it.steps[it.n - 1];
+    for (int gi = 0; gi < e->n_groups; ++gi) if (last.g[gi].M) HIP_TRY(hipEventSynchronize(e->groups[gi].ev_done[last.buf]));
+    const auto now = std::chrono::steady_clock::now();
+    const auto t0 = std::max(it.steps[0].t_begin, e->t_last_complete);
+    e->t_last_complete = now;
+    const double ms = std::chrono::duration<double, std::milli>(now - t0).count() / it.n;
+    int rc = T3_OK;
+    for (int j = 0; j < it.n; ++j) { memset(r, 0, sizeof(*r)); const int rc2 = complete_step(e, it.steps[j], r, ms); if (!rc) rc = rc2; }
+    return rc;
+}
 static int run_loop(T3Engine* e, int64_t n, int32_t* done, bool stall_is_error) {
     int rc;
     if ((rc = check_ready(e))) return rc;
     const bool ahead_ok = e->run_ahead && !e->profile && !e->cfg.debug_logits;
-    T3Engine::Step cur, nxt;
+    static thread_local Item items[2];
+    Item *cur = &items[0], *nxt = &items[1];
     T3StepResult r;
     bool have = false;
-    int64_t k = 0;
+    int64_t k = 0;            // steps completed
     rc = T3_OK;
     while (k < n && (have || t3_num_unfinished(e) > 0)) {
         if (!have) {
-            if ((rc = enqueue_step(e, cur))) break;
-            if (cur.M_all == 0) { if (stall_is_error) rc = e->fail(T3_E_NOMEM, "scheduler stalled: waiting requests cannot be admitted"); break; }
+            if ((rc = enqueue_item(e, *cur, n - k))) break;
+            if (cur->steps[0].M_all == 0) { if (stall_is_error) rc = e->fail(T3_E_NOMEM, "scheduler stalled: waiting requests cannot be admitted"); break; }
             have = true;
         }
         bool ahead = false;
-        if (ahead_ok && k + 1 < n) {
-            if ((rc = enqueue_step(e, nxt))) { memset(&r, 0, sizeof(r)); (void)complete_step(e, cur, &r); have = false; ++k; break; }
-            ahead = nxt.M_all > 0;
+        if (ahead_ok && k + cur->n < n) {
+            if ((rc = enqueue_item(e, *nxt, n - k - cur->n))) { (void)complete_item(e, *cur, &r); k += cur->n; have = false; break; }
+            ahead = nxt->steps[0].M_all > 0;
         }
-        memset(&r, 0, sizeof(r));
-        rc = complete_step(e, cur, &r);
-        have = false; ++k;
+        rc = complete_item(e, *cur, &r);
+        k += cur->n; have = false;
         if (ahead) { std::swap(cur, nxt); have = true; }
         if (rc) break;
     }
-    if (have) { memset(&r, 0, sizeof(r)); const int rc2 = complete_step(e, cur, &r); ++k; if (!rc) rc = rc2; }
+    if (have) { const int rc2 = complete_item(e, *cur, &r); k += cur->n; if (!rc) rc = rc2; }
     if (done) *done = (int32_t)k;
     return rc;
 }

@@ -71,6 +71,24 @@ extern "C" int t3k_norm_gemm(const void* h, const void* ln_w, const void* w, int
     return T3_OK;
 }
 
+/* the speech head exactly as a step launches it: final RMSNorm folded, the sampled rows gathered through row_index, bf16 logits with
+ * leading dimension 8208, the packed matrix padded to 516 n-tiles (tile groups may overhang the 8 194 columns) */
+extern "C" int t3k_head_gemm(const void* h, const void* ln_w, const void* w, int32_t M, const int32_t* row_index, int32_t Mh, void* out_bf16) {
+    if (!h || !ln_w || !w || !out_bf16 || !row_index || M <= 0 || Mh <= 0) return T3_E_INVALID;
+    if (!have_device()) return T3_E_DEVICE;
+    std::vector<uint16_t> folded((size_t)V * D), packed((size_t)HEAD_TILES * 16 * D);
+    fold_norm_weight((const uint16_t*)w, V, D, (const uint16_t*)ln_w, folded.data());
+    pack_weight(folded.data(), V, D, HEAD_TILES * 16, packed.data());
+    DevBuf dh, dw, dout, dri, drs;
+    K_TRY(dh.from(h, (size_t)Mh * D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * VPAD * 2, true));
+    K_TRY(dri.from(row_index, (size_t)M * 4)); K_TRY(drs.alloc((size_t)M * 4));
+    GemmArgs a{dh.as<uint16_t>(), dw.as<uint4>(), M, D, V, dout.p, VPAD, 4, 1, dri.as<int>(), HEAD_TILES, drs.as<float>()};
+    K_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, VPAD / 16, 4, true), nullptr));
+    K_TRY(hipDeviceSynchronize());
+    K_TRY(hipMemcpy(out_bf16, dout.p, (size_t)M * VPAD * 2, hipMemcpyDeviceToHost));
+    return T3_OK;
+}
+
 /* residual epilogue of the o_proj / down_proj form: h [M][N] bf16 updated in place: h = bf16(h + bf16(x W^T)) */
 extern "C" int t3k_gemm_resid(const void* x, const void* w, int32_t M, int32_t K, int32_t N, void* h_bf16) {
     if (!x || !w || !h_bf16 || M <= 0 || N <= 0 || N % 16 || K % 512) return T3_E_INVALID;

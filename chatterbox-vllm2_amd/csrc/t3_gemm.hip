@@ -105,8 +105,11 @@ template <int NW> constexpr int gemm2_ew() { return NW == 4 ? T3_GEMM2_EW : 0; }
 // padding was as many bytes through the CU's load path as the workgroup's weights.  The launcher picks the smallest AV whose rows
 // cover M (one m-tile, one m-group); the image rows beyond are zero (row m of the accumulator depends on image row m alone, and
 // rows >= M are never stored).  A template parameter, not a branch: conditional asm loads make hipcc build the register tuples by copies.
-template <int MT, int NT, int EPI, int NW, int KBS, bool NORM, int AV = KBS>
-__global__ __launch_bounds__((NW + gemm2_ew<NW>()) * 64) void gemm2_kernel(GemmArgs a) {
+// EWV: the epilogue waves of this instantiation (default: four for the 4-wave forms).  EWV = 0 halves the workgroup to 4 waves, so that TWO
+// workgroups fit a CU at up to 256 registers: the speech head at 64 rows is 129 tile groups x 2 row groups = 258 workgroups, and with one
+// workgroup per CU the last two ran a second, almost empty round (12.3 us for 16.8 MB against gate/up's 7.7).
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM, int AV = KBS, int EWV = gemm2_ew<NW>()>
+__global__ __launch_bounds__((NW + EWV) * 64, (NW == 4 && EWV == 0 && MT * NT >= 8) ? 2 : 1) void gemm2_kernel(GemmArgs a) {
     T3_G2STAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];      // [NW waves][MT][16 rows][KBS * 64 B] | NORM: float [NW][MT*16]
     static_assert(NT <= KBS && (KBS == 8 || KBS == 2) && (NW == 4 || NW == 16) && AV >= 1 && AV <= KBS && (AV == KBS || MT == 1), "gemm2 shapes");
@@ -125,7 +128,7 @@ __global__ __launch_bounds__((NW + gemm2_ew<NW>()) * 64) void gemm2_kernel(GemmA
         const int m = blockIdx.y * 16 + 4 * (l2 >> 4) + r, n = blockIdx.x * 16 + (l2 & 15);
         if (tid < 256 && m < a.M && n < a.N) hres = reinterpret_cast<const uint16_t*>(a.out)[(size_t)m * a.ldo + n];
     }
-    constexpr int EW = gemm2_ew<NW>();
+    constexpr int EW = EWV;
     if (EW == 0 || wave < NW) {          // the compute waves; the EW epilogue waves go straight to the barrier
     // ---- A: full row segments of this wave's K slice
     uint4_v ar[MT][KBS];
@@ -308,6 +311,171 @@ __global__ __launch_bounds__((NW + gemm2_ew<NW>()) * 64) void gemm2_kernel(GemmA
         }
     }
     T3_G2STAMP(5);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm2_split_kernel: gate/up at two (gate, up) pairs per workgroup (MT m-tiles x 4 packed n-tiles, 4 compute + 4 epilogue waves), with the
+// epilogue of the FIRST pair under the weight stream of the second.  gemm2_kernel's fold + SiLU-mul epilogue is ~300 dependent vector
+// instructions per thread with nothing in flight (0.92 us of gate/up's 5.7 at 64 rows, profiles/r03_gemm_clk_m64_epilogue_waves.txt).  Here
+// a compute wave requests pair 0's 16 weight tiles ahead of pair 1's, folds pair 0's K slice first and parks those partials in an LDS
+// region of their own (the A image is still needed); behind a workgroup barrier the four epilogue waves finish pair 0 (fold, rstd, SiLU,
+// store) while the compute waves run pair 1's MFMAs under pair 1's remaining stream; after the second barrier all eight waves share
+// pair 1's epilogue at ONE output per thread (half the dependent chain).  Same numbers as gemm2_kernel<MT, 4, EPI_SILU, 4, 8, true>:
+// every output is the same MFMA chain per segment, the same ((s0 + s1) + s2) + s3, the same rstd, the same SiLU.
+// ------------------------------------------------------------------------------------------------
+// fold + epilogue of NTL output tiles (each from a (gate, up) pair of packed tiles) whose per-wave partials [packed tile 2 to + u][r][lane]
+// start at p0 (wave w: + w * pstride floats); the workgroup's output tiles are bx * NTO_WG + to_off + to.  Thread t of nth takes pieces of CW
+// columns.  NORM SiLU form only.
+template <int MT, int NTL, int NTO_WG, int CW>
+__device__ __forceinline__ void gemm2_fold_silu(const GemmArgs& a, const float* p0, int pstride, const float* rowsum, int to_off, int t, int nth) {
+    constexpr int PPT = 16 / CW, PIECES = MT * NTL * 16 * PPT, NTP = 2 * NTL;
+    for (int p = t; p < PIECES; p += nth) {
+        const int ito = p / (16 * PPT), r16 = (p / PPT) & 15, qq = p % PPT;
+        const int i = ito / NTL, to = ito % NTL;
+        const int m = (blockIdx.y * MT + i) * 16 + r16;
+        if (m >= a.M) continue;
+        const int g = r16 >> 2, r = r16 & 3;
+        float v[2][CW];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int o = ((i * NTP + 2 * to + u) * 4 + r) * 64 + 16 * g + CW * qq;
+            if constexpr (CW == 2) {
+                const float2 s0 = *reinterpret_cast<const float2*>(p0 + o), s1 = *reinterpret_cast<const float2*>(p0 + pstride + o),
+                             s2 = *reinterpret_cast<const float2*>(p0 + 2 * pstride + o), s3 = *reinterpret_cast<const float2*>(p0 + 3 * pstride + o);
+                v[u][0] = ((s0.x + s1.x) + s2.x) + s3.x; v[u][1] = ((s0.y + s1.y) + s2.y) + s3.y;
+            } else {
+                static_assert(CW == 1 || CW == 2, "gemm2_fold_silu piece width");
+                v[u][0] = ((p0[o] + p0[pstride + o]) + p0[2 * pstride + o]) + p0[3 * pstride + o];
+            }
+        }
+        const int rl = i * 16 + r16;
+        const float ssum = ((rowsum[rl] + rowsum[MT * 16 + rl]) + rowsum[2 * MT * 16 + rl]) + rowsum[3 * MT * 16 + rl];
+        const float rstd = 1.0f / sqrtf(ssum * (1.0f / 1024.0f) + 1e-5f);
+        const int n = (blockIdx.x * NTO_WG + to_off + to) * 16 + CW * qq;
+        if (n >= a.N) continue;
+        uint32_t ob[CW];
+#pragma unroll
+        for (int e = 0; e < CW; ++e) ob[e] = silu_mul_bf(f2bf(v[0][e] * rstd), f2bf(v[1][e] * rstd));
+        uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
+        if constexpr (CW == 2) {
+            if (n + 1 < a.N || a.ldo >= ((a.N + 1) & ~1)) *reinterpret_cast<uint32_t*>(op) = ob[0] | (ob[1] << 16);
+            else op[0] = (uint16_t)ob[0];
+        } else op[0] = (uint16_t)ob[0];
+    }
+}
+template <int MT>
+__global__ __launch_bounds__(512) void gemm2_split_kernel(GemmArgs a) {
+    constexpr int NW = 4, EW = 4, KBS = 8, NT = 4, LPR = KBS * 4, RPI = 64 / LPR, ABYTES = MT * KBS * 1024;
+    constexpr int P0_FLOATS = MT * 2 * 256;                      // a wave's pair-0 partials: [MT * 2 packed tiles][4][64]
+    // LDS: [4 waves] A image | float rowsum [4][MT * 16] | 256 B prefetch dump | [4 waves] pair-0 partials
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int KB = a.K >> 5, kb0 = wave * KBS;
+    unsigned char* aimg = lds2 + (size_t)(wave & 3) * ABYTES;
+    float* rowsum = reinterpret_cast<float*>(lds2 + (size_t)NW * ABYTES);
+    unsigned char* dump_p = lds2 + (size_t)NW * ABYTES + NW * MT * 16 * sizeof(float);
+    float* part0 = reinterpret_cast<float*>(dump_p + 256);
+    if (wave < NW) {
+        uint4_v ar[MT][KBS], wr[KBS][NT];
+        const int rsub = lane / LPR, ch = lane % LPR;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < KBS; ++t) {
+                int m = (blockIdx.y * MT + i) * 16 + t * RPI + rsub;
+                m = m < a.M ? m : a.M - 1;                   // padded rows re-read the last row; their outputs are dropped
+                gload16(ar[i][t], a.X + (size_t)m * a.K + kb0 * 32 + ch * 8);
+            }
+        // pair 0's tiles of every k-block first, then pair 1's: pair 0 completes half-way through the workgroup's weight stream
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int kb = 0; kb < KBS; ++kb)
+#pragma unroll
+                for (int t = 2 * pr; t < 2 * pr + 2; ++t) gload16_nt(wr[kb][t], a.Wp + ((size_t)(blockIdx.x * NT + t) * KB + kb0 + kb) * 64 + lane);
+        wait_vmcnt<KBS * NT>();
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < KBS; ++t) landed(ar[i][t]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < KBS; ++t)
+                *reinterpret_cast<uint4_v*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(t * RPI + rsub, ch)) = ar[i][t];
+        asm volatile("" ::: "memory");
+        f32x4 acc[MT][2], ss[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) { ss[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][0] = ss[i]; acc[i][1] = ss[i]; }
+        static_for([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            uint4 af[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(c, 4 * kb + q));
+            wait_vmcnt<2 * KBS + (KBS - 1 - kb) * 2>();          // younger: pair 0's later k-blocks and all of pair 1
+            landed(wr[kb][0]); landed(wr[kb][1]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ss[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(af[i]), ss[i], 0, 0, 0);   // diagonal = sum of squares
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][0]), acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][1]), acc[i][1], 0, 0, 0);
+            }
+        }, std::make_integer_sequence<int, KBS>{});
+        float* myp0 = part0 + (size_t)wave * P0_FLOATS;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) myp0[((i * 2 + t) * 4 + r) * 64 + lane] = acc[i][t][r];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int r = c & 3;
+            const float d = r == 0 ? ss[i][0] : r == 1 ? ss[i][1] : r == 2 ? ss[i][2] : ss[i][3];
+            if ((c >> 2) == q) rowsum[wave * (MT * 16) + i * 16 + c] = d;
+        }
+        // raw barrier: pair 1's asm loads stay in flight across it (only this wave's LDS writes must be out)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < MT; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+        static_for([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            uint4 af[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(c, 4 * kb + q));
+            wait_vmcnt<(KBS - 1 - kb) * 2>();
+            landed(wr[kb][2]); landed(wr[kb][3]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][2]), acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][3]), acc[i][1], 0, 0, 0);
+            }
+        }, std::make_integer_sequence<int, KBS>{});
+        asm volatile("" ::: "memory");
+        float* redw = reinterpret_cast<float*>(aimg);             // pair 1's partials over the wave's own (now dead) A image
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) redw[((i * 2 + t) * 4 + r) * 64 + lane] = acc[i][t][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+        // epilogue waves: pair 0 while the compute waves are on pair 1
+        __builtin_amdgcn_s_barrier();
+        gemm2_fold_silu<MT, 1, 2, 2>(a, part0, P0_FLOATS, rowsum, 0, tid - NW * 64, EW * 64);
+        __builtin_amdgcn_s_barrier();
+        // every operand of the workgroup has landed and the memory system idles until the stores: the next launch's weights (PrefetchArgs)
+        if (((gridDim.x * gridDim.y) & 7) == 0) {
+            const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+            const unsigned dump = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)dump_p;
+            prefetch_next_weights(a.pf, lin & 7, (lin >> 3) * EW + (wave - NW), ((gridDim.x * gridDim.y) >> 3) * EW, lane, dump);
+        }
+    }
+    gemm2_fold_silu<MT, 1, 2, 1>(a, reinterpret_cast<const float*>(lds2), ABYTES / 4, rowsum, 1, tid, (NW + EW) * 64);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -734,10 +902,10 @@ int choose_mt(int M, int ntiles_x, int nw, bool norm) {
 }
 
 // gemm2_kernel launcher; a == nullptr: only raise the kernel's dynamic-LDS limit (prepare_kernels, before any stream capture)
-template <int MT, int NT, int EPI, int NW, int KBS, bool NORM, int AV>
+template <int MT, int NT, int EPI, int NW, int KBS, bool NORM, int AV, int EWV = gemm2_ew<NW>()>
 static hipError_t launch_gemm2_av(const GemmArgs* a, hipStream_t s) {
-    constexpr size_t lds = (size_t)NW * MT * KBS * 1024 + (NORM ? (size_t)NW * MT * 16 * sizeof(float) : 0) + (gemm2_ew<NW>() ? 256 : 0);    // + the prefetch dump corner
-    auto kern = gemm2_kernel<MT, NT, EPI, NW, KBS, NORM, AV>;
+    constexpr size_t lds = (size_t)NW * MT * KBS * 1024 + (NORM ? (size_t)NW * MT * 16 * sizeof(float) : 0) + (EWV ? 256 : 0);    // + the prefetch dump corner
+    auto kern = gemm2_kernel<MT, NT, EPI, NW, KBS, NORM, AV, EWV>;
     static bool raised[MAX_DEVICES] = {};
     if (lds > 64 * 1024 && !raised[cur_device()]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -748,7 +916,7 @@ static hipError_t launch_gemm2_av(const GemmArgs* a, hipStream_t s) {
     const int ntiles = a->packed_tiles > 0 ? a->packed_tiles / (EPI == EPI_SILU ? 2 : 1) : (a->N + 15) / 16;
     const int gx = (EPI == EPI_SILU) ? (ntiles + NT / 2 - 1) / (NT / 2) : (ntiles + NT - 1) / NT;
     const int gy = ((a->M + 15) / 16 + MT - 1) / MT;
-    launch_k(kern, dim3(gx, gy), dim3((NW + gemm2_ew<NW>()) * 64), lds, s, *a);
+    launch_k(kern, dim3(gx, gy), dim3((NW + EWV) * 64), lds, s, *a);
     return hipGetLastError();
 }
 // picks AV (see gemm2_kernel): the fewest A-row instructions that cover the rows of a one-tile call
@@ -773,6 +941,21 @@ static hipError_t launch_gemm2_t(const GemmArgs* a, hipStream_t s) {
         }
     }
     return launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, KBS>(a, s);
+}
+template <int MT>
+static hipError_t launch_gemm2_split(const GemmArgs* a, hipStream_t s) {
+    constexpr size_t lds = (size_t)4 * MT * 8 * 1024 + (size_t)4 * MT * 16 * sizeof(float) + 256 + (size_t)4 * MT * 2 * 1024;
+    auto kern = gemm2_split_kernel<MT>;
+    static bool raised[MAX_DEVICES] = {};
+    if (lds > 64 * 1024 && !raised[cur_device()]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised[cur_device()] = true;
+    }
+    if (!a) return hipSuccess;
+    const int gx = (a->N / 16 + 1) / 2, gy = ((a->M + 15) / 16 + MT - 1) / MT;
+    launch_k(kern, dim3(gx, gy), dim3(512), lds, s, *a);
+    return hipGetLastError();
 }
 // looped NORM form (>= 4 m-groups of 32 rows, no row gather): one workgroup per n-group, weights stationary in registers
 template <int MT, int NT, int EPI, int NW, int KBS, bool NORM>
@@ -803,6 +986,10 @@ static hipError_t launch_gemm2_norm(const GemmArgs* a, int epi, int mt, int nt, 
     if (epi == EPI_F32) { if (mt >= 2) T3_G2(EPI_F32, 2, 1); else T3_G2(EPI_F32, 1, 1); }
     if (epi == EPI_BF16) { if (mt >= 2) { T3_G2_NT(EPI_BF16, 2) } else { T3_G2_NT(EPI_BF16, 1) } }
     if (epi == EPI_SILU) {
+        // two (gate, up) pairs per workgroup: the first pair's epilogue under the second pair's weight stream (T3_GEMM_SPLIT_EPI=0: gemm2_kernel's one epilogue)
+        static int split = -1;
+        if (split < 0) { const char* e = getenv("T3_GEMM_SPLIT_EPI"); split = e ? atoi(e) : 1; }
+        if (split && nt == 4 && a && !a->row_index && a->N % 32 == 0 && a->packed_tiles == 0) return mt >= 2 ? launch_gemm2_split<2>(a, s) : launch_gemm2_split<1>(a, s);
         if (mt >= 2) { if (nt == 4) T3_G2(EPI_SILU, 2, 4); else T3_G2(EPI_SILU, 2, 2); }
         else { if (nt == 4) T3_G2(EPI_SILU, 1, 4); else T3_G2(EPI_SILU, 1, 2); }
     }
@@ -826,6 +1013,9 @@ hipError_t prepare_gemm2() {
     for (int epi : {EPI_F32, EPI_RESID})
         for (int kbs : {2, 8})
             if ((e = launch_gemm2_16(nullptr, epi, kbs, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_av<2, 4, EPI_BF16, 4, 8, true, 8, 0>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_split<1>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_split<2>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_t<1, 1, EPI_F32, 4, 8, false>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_t<2, 1, EPI_F32, 4, 8, false>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<2, 1, EPI_BF16, 4, 8, true>(nullptr, nullptr)) != hipSuccess) return e;
@@ -898,6 +1088,12 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
                 if ((epi != EPI_SILU || c % 2 == 0) && ntiles % c == 0 && (long)(ntiles / c) * groups >= want) pick = c;
             if (pick) nt = pick;
             if (force >= 1 && force <= 4 && (epi != EPI_SILU || force % 2 == 0) && ntiles % force == 0) nt = force;
+            // a grid a little over one round of 2 x 4 workgroups (the speech head at 64 rows: 129 x 2 = 258): the 4-wave variant of that
+            // form, two workgroups per CU, all of them resident at once (T3_GEMM_HEAD_2PERCU=0: the 2 x 3 form, 344 workgroups in 1.3 rounds)
+            static int two_per_cu = -1;
+            if (two_per_cu < 0) { const char* e = getenv("T3_GEMM_HEAD_2PERCU"); two_per_cu = e ? atoi(e) : 1; }
+            if (two_per_cu && force == 0 && epi == EPI_BF16 && mt == 2 && ntiles % 4 == 0 && partial_round(4))
+                return launch_gemm2_av<2, 4, EPI_BF16, 4, 8, true, 8, 0>(&a, s);
         }
         return launch_gemm2_norm(&a, epi, mt, nt, s);
     }

@@ -176,12 +176,14 @@ def test_profile_mode_times_every_class_and_changes_no_id(E, oracle, tiny_weight
     eng.close()
 
 
-@pytest.mark.parametrize("run_ahead", ["1", "0"])
-def test_run_ahead_with_stop_tokens(E, oracle, tiny_weights, tiny_oracle, cond, run_ahead, monkeypatch):
-    """The C++ step loop schedules step N+1 before it has read step N's tokens (DESIGN.md "Run-ahead"): an utterance
-    that emits its stop id has one discarded row pair in flight and its slot is freed one step later.  Streams must
+@pytest.mark.parametrize("run_ahead,burst", [("1", "4"), ("0", "4"), ("1", "1"), ("1", "3")])
+def test_run_ahead_with_stop_tokens(E, oracle, tiny_weights, tiny_oracle, cond, run_ahead, burst, monkeypatch):
+    """The C++ step loop schedules the next item -- a step, or a burst of up to 4 decode steps replayed as ONE graph (T3_STEPS_PER_GRAPH) --
+    before it has read the current one's tokens (DESIGN.md "Run-ahead"): an utterance that emits its stop id has discarded row pairs in
+    flight (one with single steps, up to 2 * burst - 1 with bursts) and its slot is freed when the last of them is back.  Streams must
     still end exactly at the stop id, later admissions must reuse the slots, and every KV block must come back."""
     monkeypatch.setenv("T3_RUN_AHEAD", run_ahead)
+    monkeypatch.setenv("T3_STEPS_PER_GRAPH", burst)
     eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=400, max_seqs=4, kv_bytes=1 << 29, enforce_eager=False)
     eng.load_tensors(tiny_weights); eng.finalize()
     reqs = []
@@ -201,7 +203,37 @@ def test_run_ahead_with_stop_tokens(E, oracle, tiny_weights, tiny_oracle, cond, 
         done += n
     for i, want, reason in reqs:
         got, fr = eng.get_output(i)
-        assert [t - 2500 for t in got] == want and fr == reason, f"utterance {i} (run_ahead={run_ahead})"
+        assert [t - 2500 for t in got] == want and fr == reason, f"utterance {i} (run_ahead={run_ahead}, burst={burst})"
+    st = eng.stats()
+    assert st.kv_blocks_free == st.kv_blocks_total
+    eng.close()
+
+
+@pytest.mark.parametrize("burst", ["4", "2"])
+def test_bursts_run_exactly_the_steps_asked_for(E, oracle, tiny_weights, tiny_oracle, cond, burst, monkeypatch):
+    """t3_run_steps(n) with several decode steps per graph replay: exactly n steps whatever n mod burst is (bench.py times EXACTLY K
+    steps), one token per utterance and step, length limits met in the middle of a burst window, ids equal to the oracle's."""
+    monkeypatch.setenv("T3_STEPS_PER_GRAPH", burst)
+    eng = E.T3Engine(n_layers=2, text_vocab=704, max_model_len=400, max_seqs=3, kv_bytes=1 << 29, enforce_eager=False)
+    eng.load_tensors(tiny_weights); eng.finalize()
+    reqs = []
+    for i in range(3):
+        prompt = make_prompt(5 + 3 * i, seed=20 + i)
+        kw = dict(temperature=0.8, top_p=0.8, repetition_penalty=2.0, seed=2, uid=i, max_tokens=23 + 2 * i, ignore_eos=True)      # limits 23, 25, 27
+        reqs.append((i, prompt, kw)); eng.add_request(i, prompt, cond, E.make_sampling(**kw))
+    assert eng.run_steps(1) == 1                       # the prefill step samples token 0 of all three
+    eng.reset_stats()
+    for n in (1, 5, 7, 2, 6):                          # 21 decode steps: 22 tokens each, nobody at its limit yet
+        assert eng.run_steps(n) == n
+    st = eng.stats()
+    assert st.steps == 21 and st.decode_steps == 21 and st.tokens_generated == 63
+    ms, rows = eng.step_times(64)
+    assert len(ms) == 21 and (rows == 6).all() and (ms > 0).all()
+    eng.run_until_done()
+    for i, prompt, kw in reqs:
+        got, fr = eng.get_output(i)
+        want, _ = tiny_oracle.generate(prompt, cond, oracle.make_sampling(**kw), max_model_len=400)
+        assert [t - 2500 for t in got] == want and fr == 2, f"utterance {i} (burst={burst})"
     st = eng.stats()
     assert st.kv_blocks_free == st.kv_blocks_total
     eng.close()

@@ -118,6 +118,35 @@ def test_gate_up_silu_bit_exact(E, oracle, M):
     assert_bit_equal(got, oracle.silu_mul(g, u), "silu(gate)*up with folded norm")
 
 
+@pytest.mark.parametrize("M", [17, 20, 32, 33, 63, 64])
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_gate_up_two_pairs_per_workgroup_bit_exact(E, oracle, M, split, monkeypatch):
+    """gate/up at the model's width (F = 4096, two (gate, up) pairs per workgroup at 17-64 rows): gemm2_split_kernel -- the first pair's
+    epilogue by the epilogue waves under the second pair's weight stream, the second pair's at one output per thread -- and the one-epilogue
+    form it replaces (T3_GEMM_SPLIT_EPI=0) against the oracle; ragged row counts leave a partial m-tile / m-group."""
+    monkeypatch.setenv("T3_GEMM_SPLIT_EPI", split)
+    if split == "0" and M not in (20, 64):
+        pytest.skip("the replaced form is checked at one row count per instantiation")
+    Fd = 4096
+    h = rand_bf16(M, 1024, seed=M, scale=2.0); ln = (rand_bf16(1024, seed=8) + 1.0).to(torch.bfloat16)
+    Wg = rand_bf16(Fd, 1024, seed=2, scale=0.1); Wu = rand_bf16(Fd, 1024, seed=3, scale=0.1)
+    got = E.k_silu_mul_gemm(h, ln, Wg, Wu)
+    g = oracle.norm_gemm(h, ln, Wg).to(torch.bfloat16); u = oracle.norm_gemm(h, ln, Wu).to(torch.bfloat16)
+    assert_bit_equal(got, oracle.silu_mul(g, u), f"silu(gate)*up, F=4096, M={M}, split={split}")
+
+
+@pytest.mark.parametrize("M", [2, 16, 34, 50, 64, 256])
+def test_speech_head_form_bit_exact(E, oracle, M):
+    """The speech head as a decode step of 17-32 utterances launches it: 8 194 columns (513 n-tiles, packed to 516), rows gathered through an
+    index, 2 x 4 tiles per 4-wave workgroup and two workgroups per CU (gemm2_kernel<2, 4, BF16, ..., EWV = 0>)."""
+    big = rand_bf16(M + 9, 1024, seed=M, scale=2.0); ln = (rand_bf16(1024, seed=9) + 1.0).to(torch.bfloat16)
+    W = rand_bf16(8194, 1024, seed=21, scale=0.05)
+    idx = [(5 * i + 3) % (M + 9) for i in range(M)]
+    want = oracle.norm_gemm(big[idx], ln, W).to(torch.bfloat16)
+    assert_bit_equal(E.k_head_gemm(big, ln, W, idx), want, f"speech head form M={M}")
+
+
+
 @pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8, 9, 14, 16])
 def test_decode_gemms_at_few_rows(E, oracle, M):
     """Decode steps of 1-8 utterances: the one-tile GEMMs issue only the activation-row loads that hold rows (gemm2_kernel's AV forms:

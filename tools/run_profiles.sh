@@ -12,7 +12,7 @@ python3 $R/tools/trace_gaps.py $O/p1 > $O/${TAG}_step_timeline.json
 rm -rf $O/p1
 # (2) HBM traffic: FETCH_SIZE per kernel class
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p2 -- python3 $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-profile-pass > $O/${TAG}_pmc_fetch.log 2>&1
-python3 $R/tools/pmc_summarize.py $O/p2 $O/${TAG}_pmc_fetch_size_by_kernel.json FETCH_SIZE > /dev/null
+python3 $R/tools/pmc_summarize.py $O/p2 $O/${TAG}_pmc_fetch_size_by_kernel.json FETCH_SIZE > /dev/null   # then, in the build container: python tools/update_traffic.py profiles/${TAG}_pmc_fetch_size_by_kernel.json
 rm -rf $O/p2
 # (3) MFMA counters of the prefill GEMMs (prefill-only program)
 rocprofv3 -L > $O/${TAG}_counters_available.txt 2>&1
