@@ -38,6 +38,7 @@ extern "C" int t3k_set_prefill_wide_rows(int32_t rows) { set_pgemm_wide_rows(row
 extern "C" int t3k_gemm(const void* x, const void* w, int32_t M, int32_t K, int32_t N, float* out, int32_t mt, int32_t nw) {
     if (!x || !w || !out || M <= 0 || N <= 0 || (nw != 4 && nw != 16) || !(nw == 4 ? K == D : ((K == D || K == F) && N % 16 == 0))) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
+    gemm_refresh_switches();
     const int Npad = (N + 15) / 16 * 16;
     std::vector<uint16_t> packed((size_t)Npad * K);
     pack_weight((const uint16_t*)w, N, K, Npad, packed.data());
@@ -55,6 +56,7 @@ extern "C" int t3k_norm_gemm(const void* h, const void* ln_w, const void* w, int
                              const int32_t* row_index, int32_t Mh) {
     if (!h || !ln_w || !w || !out || M <= 0 || N <= 0 || Mh <= 0) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
+    gemm_refresh_switches();
     const int Npad = (N + 15) / 16 * 16;
     std::vector<uint16_t> folded((size_t)N * D), packed((size_t)Npad * D);
     fold_norm_weight((const uint16_t*)w, N, D, (const uint16_t*)ln_w, folded.data());      // what the engine does once at load time
@@ -71,11 +73,29 @@ extern "C" int t3k_norm_gemm(const void* h, const void* ln_w, const void* w, int
     return T3_OK;
 }
 
+/* the qkv projection exactly as a step launches it: input RMSNorm folded, bf16 out [M][3072] */
+extern "C" int t3k_qkv_gemm(const void* h, const void* ln_w, const void* w, int32_t M, void* out_bf16) {
+    if (!h || !ln_w || !w || !out_bf16 || M <= 0) return T3_E_INVALID;
+    if (!have_device()) return T3_E_DEVICE;
+    gemm_refresh_switches();
+    std::vector<uint16_t> folded((size_t)QKV * D), packed((size_t)QKV * D);
+    fold_norm_weight((const uint16_t*)w, QKV, D, (const uint16_t*)ln_w, folded.data());
+    pack_weight(folded.data(), QKV, D, QKV, packed.data());
+    DevBuf dh, dw, dout, drs;
+    K_TRY(dh.from(h, (size_t)M * D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * QKV * 2, true)); K_TRY(drs.alloc((size_t)M * 4));
+    GemmArgs a{dh.as<uint16_t>(), dw.as<uint4>(), M, D, QKV, dout.p, QKV, 4, 1, nullptr, 0, drs.as<float>()};
+    K_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, QKV / 16, 4, true), nullptr));
+    K_TRY(hipDeviceSynchronize());
+    K_TRY(hipMemcpy(out_bf16, dout.p, (size_t)M * QKV * 2, hipMemcpyDeviceToHost));
+    return T3_OK;
+}
+
 /* the speech head exactly as a step launches it: final RMSNorm folded, the sampled rows gathered through row_index, bf16 logits with
  * leading dimension 8208, the packed matrix padded to 516 n-tiles (tile groups may overhang the 8 194 columns) */
 extern "C" int t3k_head_gemm(const void* h, const void* ln_w, const void* w, int32_t M, const int32_t* row_index, int32_t Mh, void* out_bf16) {
     if (!h || !ln_w || !w || !out_bf16 || !row_index || M <= 0 || Mh <= 0) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
+    gemm_refresh_switches();
     std::vector<uint16_t> folded((size_t)V * D), packed((size_t)HEAD_TILES * 16 * D);
     fold_norm_weight((const uint16_t*)w, V, D, (const uint16_t*)ln_w, folded.data());
     pack_weight(folded.data(), V, D, HEAD_TILES * 16, packed.data());
@@ -93,6 +113,7 @@ extern "C" int t3k_head_gemm(const void* h, const void* ln_w, const void* w, int
 extern "C" int t3k_gemm_resid(const void* x, const void* w, int32_t M, int32_t K, int32_t N, void* h_bf16) {
     if (!x || !w || !h_bf16 || M <= 0 || N <= 0 || N % 16 || K % 512) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
+    gemm_refresh_switches();
     std::vector<uint16_t> packed((size_t)N * K);
     pack_weight((const uint16_t*)w, N, K, N, packed.data());
     DevBuf dx, dw, dh;
@@ -108,6 +129,7 @@ extern "C" int t3k_gemm_resid(const void* x, const void* w, int32_t M, int32_t K
 extern "C" int t3k_silu_mul_gemm(const void* h, const void* ln_w, const void* wg, const void* wu, int32_t M, int32_t Fd, void* out) {
     if (!h || !ln_w || !wg || !wu || !out || M <= 0 || Fd <= 0 || Fd % 16) return T3_E_INVALID;
     if (!have_device()) return T3_E_DEVICE;
+    gemm_refresh_switches();
     std::vector<uint16_t> fg((size_t)Fd * D), fu((size_t)Fd * D), packed((size_t)2 * Fd * D);
     fold_norm_weight((const uint16_t*)wg, Fd, D, (const uint16_t*)ln_w, fg.data());
     fold_norm_weight((const uint16_t*)wu, Fd, D, (const uint16_t*)ln_w, fu.data());

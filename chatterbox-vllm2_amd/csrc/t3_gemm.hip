@@ -108,6 +108,9 @@ template <int NW> constexpr int gemm2_ew() { return NW == 4 ? T3_GEMM2_EW : 0; }
 // EWV: the epilogue waves of this instantiation (default: four for the 4-wave forms).  EWV = 0 halves the workgroup to 4 waves, so that TWO
 // workgroups fit a CU at up to 256 registers: the speech head at 64 rows is 129 tile groups x 2 row groups = 258 workgroups, and with one
 // workgroup per CU the last two ran a second, almost empty round (12.3 us for 16.8 MB against gate/up's 7.7).
+// k-blocks of A fragments in flight from LDS ahead of the MFMAs (gemm2_kernel's K loop): every one of them where the registers are there
+// (one m-tile: 4 registers per k-block), two k-blocks ahead for the two-m-tile forms (up to 228 registers already)
+template <int MT, int NT, int KBS> constexpr int gemm2_afd() { return MT == 1 ? KBS : (MT * NT >= 8 ? 2 : 4) < KBS ? (MT * NT >= 8 ? 2 : 4) : KBS; }
 template <int MT, int NT, int EPI, int NW, int KBS, bool NORM, int AV = KBS, int EWV = gemm2_ew<NW>()>
 __global__ __launch_bounds__((NW + EWV) * 64, (NW == 4 && EWV == 0 && MT * NT >= 8) ? 2 : 1) void gemm2_kernel(GemmArgs a) {
     T3_G2STAMP(0);
@@ -181,22 +184,31 @@ __global__ __launch_bounds__((NW + EWV) * 64, (NW == 4 && EWV == 0 && MT * NT >=
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    // The A fragments of the next AFD k-blocks are requested from LDS ahead of the MFMAs that use them.  Read per k-block right before its
+    // MFMAs (rounds 2-3), a k-block cost an LDS round trip (~130-200 cycles) that only its own few MFMAs could cover: the 16-wave forms (ONE
+    // MFMA per k-block) and qkv spent 0.5-0.8 us between "rows staged" and "last MFMA" (profiles/r03_gemm_clk_m64.txt) for 8-32 MFMAs.
+    constexpr int AFD = gemm2_afd<MT, NT, KBS>();
+    uint4 afr[AFD][MT];
+    auto read_af = [&](int slot, int kb) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) afr[slot][i] = *reinterpret_cast<const uint4*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(c, 4 * kb + q));
+    };
+    static_for([&](auto dc) { read_af(decltype(dc)::value, decltype(dc)::value); }, std::make_integer_sequence<int, AFD>{});
     static_for([&](auto kbc) {
         constexpr int kb = decltype(kbc)::value;
-        uint4 af[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(c, 4 * kb + q));
         wait_vmcnt<(KBS - 1 - kb) * NT>();            // this k-block's NT weight tiles have landed ((KBS - 1 - kb) * NT younger loads may still fly)
 #pragma unroll
         for (int t = 0; t < NT; ++t) landed(wr[kb][t]);
         if constexpr (kb == 0) T3_G2STAMP(2);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            if constexpr (NORM) ss[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(af[i]), ss[i], 0, 0, 0);   // diagonal = sum of squares
+            const uint4 af = afr[kb % AFD][i];
+            if constexpr (NORM) ss[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag(af), ss[i], 0, 0, 0);   // diagonal = sum of squares
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][t]), acc[i][t], 0, 0, 0);
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag4(wr[kb][t]), acc[i][t], 0, 0, 0);
         }
+        if constexpr (kb + AFD < KBS) read_af(kb % AFD, kb + AFD);
     }, std::make_integer_sequence<int, KBS>{});
     T3_G2STAMP(3);
     // ---- partials over the wave's own (now dead) A image: [tile][r][lane]
@@ -314,31 +326,27 @@ __global__ __launch_bounds__((NW + EWV) * 64, (NW == 4 && EWV == 0 && MT * NT >=
 }
 
 // ------------------------------------------------------------------------------------------------
-// gemm2_split_kernel: gate/up at two (gate, up) pairs per workgroup (MT m-tiles x 4 packed n-tiles, 4 compute + 4 epilogue waves), with the
-// epilogue of the FIRST pair under the weight stream of the second.  gemm2_kernel's fold + SiLU-mul epilogue is ~300 dependent vector
-// instructions per thread with nothing in flight (0.92 us of gate/up's 5.7 at 64 rows, profiles/r03_gemm_clk_m64_epilogue_waves.txt).  Here
-// a compute wave requests pair 0's 16 weight tiles ahead of pair 1's, folds pair 0's K slice first and parks those partials in an LDS
-// region of their own (the A image is still needed); behind a workgroup barrier the four epilogue waves finish pair 0 (fold, rstd, SiLU,
-// store) while the compute waves run pair 1's MFMAs under pair 1's remaining stream; after the second barrier all eight waves share
-// pair 1's epilogue at ONE output per thread (half the dependent chain).  Same numbers as gemm2_kernel<MT, 4, EPI_SILU, 4, 8, true>:
-// every output is the same MFMA chain per segment, the same ((s0 + s1) + s2) + s3, the same rstd, the same SiLU.
+// Fold + epilogue shared by the pipelined forms below (and by tools/diag/gemm2_split_kernel.inc, the measured-and-rejected variant with
+// the first (gate, up) pair's epilogue under the second pair's weight stream: 0.6 % slower at C3, profiles/NOTES.md).
 // ------------------------------------------------------------------------------------------------
 // fold + epilogue of NTL output tiles (each from a (gate, up) pair of packed tiles) whose per-wave partials [packed tile 2 to + u][r][lane]
-// start at p0 (wave w: + w * pstride floats); the workgroup's output tiles are bx * NTO_WG + to_off + to.  Thread t of nth takes pieces of CW
-// columns.  NORM SiLU form only.
-template <int MT, int NTL, int NTO_WG, int CW>
-__device__ __forceinline__ void gemm2_fold_silu(const GemmArgs& a, const float* p0, int pstride, const float* rowsum, int to_off, int t, int nth) {
-    constexpr int PPT = 16 / CW, PIECES = MT * NTL * 16 * PPT, NTP = 2 * NTL;
+// start at p0 (wave w: + w * pstride floats); the workgroup's output tiles are bx * NTO_WG + to_off + to, its m-tiles mt0 .. mt0 + MT - 1.
+// Thread t of nth takes pieces of CW columns.  NORM SiLU form only.
+template <int MT, int NTL, int NTO_WG, int CW, int EPI = EPI_SILU>
+__device__ __forceinline__ void gemm2_fold_silu(const GemmArgs& a, const float* p0, int pstride, const float* rowsum, int to_off, int t, int nth, int mt0) {
+    static_assert(EPI == EPI_SILU || EPI == EPI_BF16, "gemm2_fold_silu epilogues");
+    constexpr int NU = EPI == EPI_SILU ? 2 : 1;               // packed tiles per output tile: a (gate, up) pair, or the tile itself (EPI_BF16)
+    constexpr int PPT = 16 / CW, PIECES = MT * NTL * 16 * PPT, NTP = NU * NTL;
     for (int p = t; p < PIECES; p += nth) {
         const int ito = p / (16 * PPT), r16 = (p / PPT) & 15, qq = p % PPT;
         const int i = ito / NTL, to = ito % NTL;
-        const int m = (blockIdx.y * MT + i) * 16 + r16;
+        const int m = (mt0 + i) * 16 + r16;
         if (m >= a.M) continue;
         const int g = r16 >> 2, r = r16 & 3;
         float v[2][CW];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int o = ((i * NTP + 2 * to + u) * 4 + r) * 64 + 16 * g + CW * qq;
+        for (int u = 0; u < NU; ++u) {
+            const int o = ((i * NTP + NU * to + u) * 4 + r) * 64 + 16 * g + CW * qq;
             if constexpr (CW == 2) {
                 const float2 s0 = *reinterpret_cast<const float2*>(p0 + o), s1 = *reinterpret_cast<const float2*>(p0 + pstride + o),
                              s2 = *reinterpret_cast<const float2*>(p0 + 2 * pstride + o), s3 = *reinterpret_cast<const float2*>(p0 + 3 * pstride + o);
@@ -355,7 +363,7 @@ __device__ __forceinline__ void gemm2_fold_silu(const GemmArgs& a, const float* 
         if (n >= a.N) continue;
         uint32_t ob[CW];
 #pragma unroll
-        for (int e = 0; e < CW; ++e) ob[e] = silu_mul_bf(f2bf(v[0][e] * rstd), f2bf(v[1][e] * rstd));
+        for (int e = 0; e < CW; ++e) ob[e] = EPI == EPI_SILU ? silu_mul_bf(f2bf(v[0][e] * rstd), f2bf(v[NU - 1][e] * rstd)) : f2bf(v[0][e] * rstd);
         uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
         if constexpr (CW == 2) {
             if (n + 1 < a.N || a.ldo >= ((a.N + 1) & ~1)) *reinterpret_cast<uint32_t*>(op) = ob[0] | (ob[1] << 16);
@@ -363,119 +371,205 @@ __device__ __forceinline__ void gemm2_fold_silu(const GemmArgs& a, const float* 
         } else op[0] = (uint16_t)ob[0];
     }
 }
-template <int MT>
-__global__ __launch_bounds__(512) void gemm2_split_kernel(GemmArgs a) {
-    constexpr int NW = 4, EW = 4, KBS = 8, NT = 4, LPR = KBS * 4, RPI = 64 / LPR, ABYTES = MT * KBS * 1024;
-    constexpr int P0_FLOATS = MT * 2 * 256;                      // a wave's pair-0 partials: [MT * 2 packed tiles][4][64]
-    // LDS: [4 waves] A image | float rowsum [4][MT * 16] | 256 B prefetch dump | [4 waves] pair-0 partials
+// ------------------------------------------------------------------------------------------------
+// gemm2_pipe_kernel: gate/up from 81 rows on (decode steps of 41+ utterances; C4 runs at 256 rows).  Weights stationary as in
+// gemm2_loop_kernel -- a workgroup owns two (gate, up) pairs = 4 packed n-tiles, 128 registers per compute wave, and a share of the
+// 16-row groups -- but the groups are PIPELINED through two wave sets instead of walked serially: the four compute waves run group
+// j + 1 on the matrix cores while the four epilogue waves fold, normalise, SiLU-multiply and store group j.  The looped form spent ~5 of
+// its 16.6 us at 256 rows in four serial epilogues (~300 dependent vector instructions per thread, nothing else running on the CU) and
+// had no registers left for epilogue waves (4 stationary tiles + 64 registers of rows in flight = 256 + 44 spill-over AGPRs).  Here
+//   * the activation rows come by LDS-DMA straight into a wave-private, double-buffered, XOR-swizzled A image (the swizzle is applied to
+//     the SOURCE address: a DMA piece writes LDS linearly), two groups ahead, so no row ever sits in a register: ~170 registers, 8 waves;
+//   * partials and row statistics go to a double-buffered exchange area; ONE workgroup barrier per group hands group j to the epilogue
+//     waves and, because they reach it only after finishing group j - 1, also frees buffer (j + 1) & 1 for the compute waves.
+// Same numbers as gemm2_kernel: per (row, column) the same MFMA chain per segment, ((s0 + s1) + s2) + s3, rstd, SiLU.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr);
+// NT packed n-tiles per workgroup: 4 = two (gate, up) pairs (EPI_SILU), or 3 / 4 plain tiles (EPI_BF16: qkv)
+template <int NT, int EPI>
+__global__ __launch_bounds__(512) void gemm2_pipe_kernel(GemmArgs a) {
+    constexpr int NW = 4, EW = 4, KBS = 8, AIMG = 16 * KBS * 64;                  // a wave's A image of one group: 16 rows x 512 B = 8 KiB
+    constexpr int NTO = EPI == EPI_SILU ? NT / 2 : NT;                              // output tiles per workgroup
+    constexpr int PFL = NT * 256;                                                   // a wave's partials of one group: [4 packed tiles][4][64] floats
+    // LDS: [2 buffers][4 waves] A image (64 KiB) | [2][4 waves] partials (32 KiB) | [2][4][16] row statistic
     extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* pbase = reinterpret_cast<float*>(lds2 + 2 * NW * AIMG);
+    float* rbase = pbase + 2 * NW * PFL;
+    const int mgroups = (a.M + 15) / 16;
+    const int g0 = blockIdx.y, gs = gridDim.y;                  // this workgroup's groups: g0, g0 + gs, ...
+    const int ng = g0 < mgroups ? (mgroups - g0 + gs - 1) / gs : 0;
+    if (ng == 0) return;
+    if (wave >= NW) {
+        for (int j = 0; j < ng; ++j) {
+            __builtin_amdgcn_s_barrier();                        // group j's partials are complete (and the compute waves may take buffer (j + 1) & 1)
+            gemm2_fold_silu<1, NTO, NTO, 2, EPI>(a, pbase + (size_t)(j & 1) * NW * PFL, PFL, rbase + (j & 1) * NW * 16, 0, tid - NW * 64, EW * 64, g0 + j * gs);
+        }
+        return;
+    }
     const int c = lane & 15, q = lane >> 4;
     const int KB = a.K >> 5, kb0 = wave * KBS;
-    unsigned char* aimg = lds2 + (size_t)(wave & 3) * ABYTES;
-    float* rowsum = reinterpret_cast<float*>(lds2 + (size_t)NW * ABYTES);
-    unsigned char* dump_p = lds2 + (size_t)NW * ABYTES + NW * MT * 16 * sizeof(float);
-    float* part0 = reinterpret_cast<float*>(dump_p + 256);
-    if (wave < NW) {
-        uint4_v ar[MT][KBS], wr[KBS][NT];
-        const int rsub = lane / LPR, ch = lane % LPR;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds2;
+    // DMA piece t of a group covers image rows 2 t, 2 t + 1: lane l fills position p = l % 32 of row 2 t + l / 32, which holds the row's
+    // 16-byte chunk p ^ (row & 15) (a_img_off<8>): the permutation stays inside the row's 512 bytes, whole 128-byte lines are fetched
+    const int drow = lane >> 5, dpos = lane & 31;
+    auto issue_a = [&](int g, int buf) {
+        const unsigned img = lds0 + (unsigned)((buf * NW + wave) * AIMG);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int t = 0; t < 8; ++t) {
+            const int row = 2 * t + drow;
+            int m = g * 16 + row; m = m < a.M ? m : a.M - 1;     // padded rows re-read the last row; their outputs are dropped
+            glds16(a.X + (size_t)m * a.K + kb0 * 32 + ((dpos ^ (row & 15)) << 3), img + t * 1024);
+        }
+    };
+    uint4_v wr[KBS][NT];
+    issue_a(g0, 0);
 #pragma unroll
-            for (int t = 0; t < KBS; ++t) {
-                int m = (blockIdx.y * MT + i) * 16 + t * RPI + rsub;
-                m = m < a.M ? m : a.M - 1;                   // padded rows re-read the last row; their outputs are dropped
-                gload16(ar[i][t], a.X + (size_t)m * a.K + kb0 * 32 + ch * 8);
-            }
-        // pair 0's tiles of every k-block first, then pair 1's: pair 0 completes half-way through the workgroup's weight stream
+    for (int kb = 0; kb < KBS; ++kb)
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr)
+        for (int t = 0; t < NT; ++t) gload16_nt(wr[kb][t], a.Wp + ((size_t)(blockIdx.x * NT + t) * KB + kb0 + kb) * 64 + lane);
+    if (ng > 1) issue_a(g0 + gs, 1);
+    for (int j = 0; j < ng; ++j) {
+        const unsigned char* aimg = lds2 + (size_t)((j & 1) * NW + wave) * AIMG;
+        const bool next_in_flight = j + 1 < ng;                  // the next group's 8 pieces are younger than this group's
+        // this group's rows have landed (j = 0: the 32 weight tiles are younger too, and are waited for k-block by k-block below)
+        if (j == 0) { if (next_in_flight) wait_vmcnt<KBS * NT + 8>(); else wait_vmcnt<KBS * NT>(); }
+        else { if (next_in_flight) wait_vmcnt<8>(); else wait_vmcnt<0>(); }
+        f32x4 acc[NT], ss = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kb = 0; kb < KBS; ++kb)
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        uint4 afr[KBS];                                          // every A fragment of the group requested ahead of the MFMAs (see gemm2_kernel)
 #pragma unroll
-                for (int t = 2 * pr; t < 2 * pr + 2; ++t) gload16_nt(wr[kb][t], a.Wp + ((size_t)(blockIdx.x * NT + t) * KB + kb0 + kb) * 64 + lane);
-        wait_vmcnt<KBS * NT>();
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int t = 0; t < KBS; ++t) landed(ar[i][t]);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int t = 0; t < KBS; ++t)
-                *reinterpret_cast<uint4_v*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(t * RPI + rsub, ch)) = ar[i][t];
-        asm volatile("" ::: "memory");
-        f32x4 acc[MT][2], ss[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) { ss[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][0] = ss[i]; acc[i][1] = ss[i]; }
+        for (int kb = 0; kb < KBS; ++kb) afr[kb] = *reinterpret_cast<const uint4*>(aimg + a_img_off<KBS>(c, 4 * kb + q));
         static_for([&](auto kbc) {
             constexpr int kb = decltype(kbc)::value;
-            uint4 af[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(c, 4 * kb + q));
-            wait_vmcnt<2 * KBS + (KBS - 1 - kb) * 2>();          // younger: pair 0's later k-blocks and all of pair 1
-            landed(wr[kb][0]); landed(wr[kb][1]);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                ss[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(af[i]), ss[i], 0, 0, 0);   // diagonal = sum of squares
-                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][0]), acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][1]), acc[i][1], 0, 0, 0);
+            const uint4 af = afr[kb];
+            if (j == 0) {
+                if (next_in_flight) wait_vmcnt<(KBS - 1 - kb) * NT + 8>(); else wait_vmcnt<(KBS - 1 - kb) * NT>();
             }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) landed(wr[kb][t]);
+            ss = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag(af), ss, 0, 0, 0);       // diagonal = sum of squares
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag4(wr[kb][t]), acc[t], 0, 0, 0);
         }, std::make_integer_sequence<int, KBS>{});
-        float* myp0 = part0 + (size_t)wave * P0_FLOATS;
+        float* myp = pbase + (size_t)((j & 1) * NW + wave) * PFL;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) myp0[((i * 2 + t) * 4 + r) * 64 + lane] = acc[i][t][r];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
+            for (int r = 0; r < 4; ++r) myp[(t * 4 + r) * 64 + lane] = acc[t][r];
+        {
             const int r = c & 3;
-            const float d = r == 0 ? ss[i][0] : r == 1 ? ss[i][1] : r == 2 ? ss[i][2] : ss[i][3];
-            if ((c >> 2) == q) rowsum[wave * (MT * 16) + i * 16 + c] = d;
+            const float d = r == 0 ? ss[0] : r == 1 ? ss[1] : r == 2 ? ss[2] : ss[3];
+            if ((c >> 2) == q) rbase[((j & 1) * NW + wave) * 16 + c] = d;
         }
-        // raw barrier: pair 1's asm loads stay in flight across it (only this wave's LDS writes must be out)
+        // raw barrier: the next group's DMA pieces stay in flight across it; this wave's LDS writes must be out and its reads of the A
+        // image are (the MFMAs consumed them), so the image may be refilled right behind the barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (j + 2 < ng) issue_a(g0 + (j + 2) * gs, j & 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm2_pipe16_kernel: gate/up's pipelined form at 16 waves per workgroup.  In gemm2_pipe_kernel<4, EPI_SILU> the four epilogue waves set
+// the pace: a group's 512 outputs at two per thread are ~215 dependent vector instructions per wave, ~1.0 us, against ~0.4 us of matrix
+// work (tools/gemm_bench: +4.2 us per 128 rows).  Epilogue waves are only as many as the registers allow, and a compute wave that holds
+// two pairs' weight tiles needs 197.  Here the two (gate, up) pairs go to two SETS of four compute waves (64 registers of weights each,
+// the two sets share the A images: the set of pair 0 requests them, its statistic is the row statistic), which leaves room for EIGHT
+// epilogue waves at <= 128 registers: one output per thread, four waves per SIMD to fill the issue slots.  One barrier per group as before;
+// a wave of set 0 makes sure the next group's rows have landed before it enters the barrier behind which set 1 reads them.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gemm2_pipe16_kernel(GemmArgs a) {
+    constexpr int NS = 4, KBS = 8, AIMG = 16 * KBS * 64;                          // K segments; a segment's A image of one group: 16 rows x 512 B
+    constexpr int NA = 3;                                                           // A buffers: a group's rows are asked for TWO groups ahead (an L2 round trip under load is about one group)
+    constexpr int PFL = 2 * 256;                                                    // a compute wave's partials of one group: [gate | up][4][64] floats
+    // LDS: [3 buffers][4 segments] A image (96 KiB) | [2][2 pairs][4 segments] partials (32 KiB) | [2][4][16] row statistic
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* pbase = reinterpret_cast<float*>(lds2 + NA * NS * AIMG);
+    float* rbase = pbase + 2 * 2 * NS * PFL;
+    const int mgroups = (a.M + 15) / 16;
+    const int g0 = blockIdx.y, gs = gridDim.y;
+    const int ng = g0 < mgroups ? (mgroups - g0 + gs - 1) / gs : 0;
+    if (ng == 0) return;
+    if (wave >= 8) {
+        const int te = tid - 512, pair = te >> 8;
+        __builtin_amdgcn_s_barrier();                            // the first group's rows are in (compute waves only)
+        for (int j = 0; j < ng; ++j) {
+            __builtin_amdgcn_s_barrier();                        // group j's partials are complete
+            gemm2_fold_silu<1, 1, 2, 1>(a, pbase + (size_t)((j & 1) * 2 + pair) * NS * PFL, PFL, rbase + (j & 1) * NS * 16, pair, te & 255, 256, g0 + j * gs);
+        }
+        return;
+    }
+    const int seg = wave & 3, pair = wave >> 2;
+    const int c = lane & 15, q = lane >> 4;
+    const int KB = a.K >> 5, kb0 = seg * KBS;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds2;
+    const int drow = lane >> 5, dpos = lane & 31;
+    auto issue_a = [&](int g, int buf) {                        // set 0 only: see gemm2_pipe_kernel
+        const unsigned img = lds0 + (unsigned)((buf * NS + seg) * AIMG);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+        for (int t = 0; t < 8; ++t) {
+            const int row = 2 * t + drow;
+            int m = g * 16 + row; m = m < a.M ? m : a.M - 1;
+            glds16(a.X + (size_t)m * a.K + kb0 * 32 + ((dpos ^ (row & 15)) << 3), img + t * 1024);
+        }
+    };
+    // younger = 8 * ahead + BASE: waits of set 0 while `ahead` (0, 1 or 2) later groups' pieces are in flight behind what is waited for
+    auto wait_ahead = [&](int ahead, auto base_c) {
+        constexpr int BASE = decltype(base_c)::value;
+        if (ahead == 2) wait_vmcnt<BASE + 16>(); else if (ahead == 1) wait_vmcnt<BASE + 8>(); else wait_vmcnt<BASE>();
+    };
+    uint4_v wr[KBS][2];
+    if (pair == 0) issue_a(g0, 0);
+#pragma unroll
+    for (int kb = 0; kb < KBS; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) gload16_nt(wr[kb][t], a.Wp + ((size_t)(blockIdx.x * 4 + 2 * pair + t) * KB + kb0 + kb) * 64 + lane);
+    const int ahead0 = pair == 0 ? (ng > 2 ? 2 : ng - 1) : 0;    // groups asked for behind the weights in the prologue
+    if (pair == 0) {
+        if (ng > 1) issue_a(g0 + gs, 1);
+        if (ng > 2) issue_a(g0 + 2 * gs, 2);
+        wait_ahead(ahead0, std::integral_constant<int, 2 * KBS>{});      // the first group's rows have landed
+    }
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (int j = 0; j < ng; ++j) {
+        const unsigned char* aimg = lds2 + (size_t)(buf * NS + seg) * AIMG;
+        f32x4 acc[2], ss = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[0] = ss; acc[1] = ss;
+        constexpr int AFD = 3;                                   // A fragments this many k-blocks ahead of their MFMAs (see gemm2_kernel; 128 registers here)
+        uint4 afr[AFD];
+#pragma unroll
+        for (int d = 0; d < AFD; ++d) afr[d] = *reinterpret_cast<const uint4*>(aimg + a_img_off<KBS>(c, 4 * d + q));
         static_for([&](auto kbc) {
             constexpr int kb = decltype(kbc)::value;
-            uint4 af[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(c, 4 * kb + q));
-            wait_vmcnt<(KBS - 1 - kb) * 2>();
-            landed(wr[kb][2]); landed(wr[kb][3]);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][2]), acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][3]), acc[i][1], 0, 0, 0);
-            }
+            const uint4 af = afr[kb % AFD];
+            if constexpr (kb + AFD < KBS) afr[kb % AFD] = *reinterpret_cast<const uint4*>(aimg + a_img_off<KBS>(c, 4 * (kb + AFD) + q));
+            if (j == 0) wait_ahead(ahead0, std::integral_constant<int, (KBS - 1 - kb) * 2>{});
+            landed(wr[kb][0]); landed(wr[kb][1]);
+            if (pair == 0) ss = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag(af), ss, 0, 0, 0);       // diagonal = sum of squares
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag4(wr[kb][0]), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag4(wr[kb][1]), acc[1], 0, 0, 0);
         }, std::make_integer_sequence<int, KBS>{});
-        asm volatile("" ::: "memory");
-        float* redw = reinterpret_cast<float*>(aimg);             // pair 1's partials over the wave's own (now dead) A image
+        float* myp = pbase + (size_t)(((j & 1) * 2 + pair) * NS + seg) * PFL;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) redw[((i * 2 + t) * 4 + r) * 64 + lane] = acc[i][t][r];
+            for (int r = 0; r < 4; ++r) myp[(t * 4 + r) * 64 + lane] = acc[t][r];
+        if (pair == 0) {
+            const int r = c & 3;
+            const float d = r == 0 ? ss[0] : r == 1 ? ss[1] : r == 2 ? ss[2] : ss[3];
+            if ((c >> 2) == q) rbase[((j & 1) * NS + seg) * 16 + c] = d;
+            // group j + 1's rows (asked for two groups ago) are in LDS before set 1 may read them; group j + 2's may still fly
+            if (j + 2 < ng) wait_vmcnt<8>(); else wait_vmcnt<0>();
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-    } else {
-        // epilogue waves: pair 0 while the compute waves are on pair 1
-        __builtin_amdgcn_s_barrier();
-        gemm2_fold_silu<MT, 1, 2, 2>(a, part0, P0_FLOATS, rowsum, 0, tid - NW * 64, EW * 64);
-        __builtin_amdgcn_s_barrier();
-        // every operand of the workgroup has landed and the memory system idles until the stores: the next launch's weights (PrefetchArgs)
-        if (((gridDim.x * gridDim.y) & 7) == 0) {
-            const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-            const unsigned dump = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)dump_p;
-            prefetch_next_weights(a.pf, lin & 7, (lin >> 3) * EW + (wave - NW), ((gridDim.x * gridDim.y) >> 3) * EW, lane, dump);
-        }
+        if (pair == 0 && j + 3 < ng) issue_a(g0 + (j + 3) * gs, buf);      // into the image every wave has just finished reading
+        buf = buf == NA - 1 ? 0 : buf + 1;
     }
-    gemm2_fold_silu<MT, 1, 2, 1>(a, reinterpret_cast<const float*>(lds2), ABYTES / 4, rowsum, 1, tid, (NW + EW) * 64);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -531,11 +625,16 @@ __global__ __launch_bounds__(NW * 64) void gemm2_loop_kernel(GemmArgs a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        // A fragments AFD k-blocks ahead of their MFMAs (see gemm2_kernel); the two-m-tile forms are at the register file's limit: one ahead
+        constexpr int AFD = MT == 1 ? KBS : 1;
+        uint4 afr[AFD][MT];
+        auto read_af = [&](int slot, int kb) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) afr[slot][i] = *reinterpret_cast<const uint4*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(c, 4 * kb + q));
+        };
+        static_for([&](auto dc) { read_af(decltype(dc)::value, decltype(dc)::value); }, std::make_integer_sequence<int, AFD>{});
         static_for([&](auto kbc) {
             constexpr int kb = decltype(kbc)::value;
-            uint4 af[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(aimg + i * (KBS * 1024) + a_img_off<KBS>(c, 4 * kb + q));
             if constexpr (FIRST) {     // the weights land during the first group: younger = the later weight tiles + the next group's rows
                 wait_vmcnt<(KBS - 1 - kb) * NT + MT * KBS>();
 #pragma unroll
@@ -543,11 +642,13 @@ __global__ __launch_bounds__(NW * 64) void gemm2_loop_kernel(GemmArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                if constexpr (NORM) ss[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(af[i]), ss[i], 0, 0, 0);
+                const uint4 af = afr[kb % AFD][i];
+                if constexpr (NORM) ss[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag(af), ss[i], 0, 0, 0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag4(wr[kb][t]), acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag4(wr[kb][t]), acc[i][t], 0, 0, 0);
             }
+            if constexpr (kb + AFD < KBS) read_af(kb % AFD, kb + AFD);
         }, std::make_integer_sequence<int, KBS>{});
         asm volatile("" ::: "memory");
         float* redw = reinterpret_cast<float*>(aimg);
@@ -699,7 +800,7 @@ __device__ __forceinline__ int pgemm_a_pos(int row, int q) { return (row << 2) +
 // one 1 KiB LDS-DMA piece: every lane's 16 bytes at gsrc land at lds_byte_addr (wave-uniform) + 16 * lane.  M0 carries the LDS
 // address and is written in the statement that uses it (cdna_hip_programming.md 5.7); hipcc does not count this load: every wait
 // for it below is hand-counted.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr) {
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr) {      // (declared ahead of gemm2_pipe_kernel)
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
@@ -846,6 +947,7 @@ __global__ __launch_bounds__(256, WC == 4 ? 2 : (NSEG == 4 ? 4 : 3)) void pgemm_
 }
 
 static int g_pgemm_min_rows = -1, g_pgemm_wide_rows = -1;
+static int g_gemm_pipe = 1, g_gemm_head_2percu = 1, g_gemm_pipe_qkv_min = 129;      // T3_GEMM_PIPE / T3_GEMM_HEAD_2PERCU / T3_GEMM_PIPE_QKV_MIN_ROWS (measurement switches, re-read with the next one)
 static int g_gemm_small_m = 1;          // T3_GEMM_SMALL_M=0: the one-tile GEMMs issue every activation-row load (read again by every prepare_kernels call, i.e. per engine)
 void set_pgemm_min_rows(int rows) { g_pgemm_min_rows = rows; }
 void set_pgemm_wide_rows(int rows) { g_pgemm_wide_rows = rows; }
@@ -942,18 +1044,40 @@ static hipError_t launch_gemm2_t(const GemmArgs* a, hipStream_t s) {
     }
     return launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, KBS>(a, s);
 }
-template <int MT>
-static hipError_t launch_gemm2_split(const GemmArgs* a, hipStream_t s) {
-    constexpr size_t lds = (size_t)4 * MT * 8 * 1024 + (size_t)4 * MT * 16 * sizeof(float) + 256 + (size_t)4 * MT * 2 * 1024;
-    auto kern = gemm2_split_kernel<MT>;
+static hipError_t launch_gemm2_pipe16(const GemmArgs* a, hipStream_t s) {
+    constexpr size_t lds = (size_t)3 * 4 * 8192 + (size_t)2 * 2 * 4 * 2048 + (size_t)2 * 4 * 16 * sizeof(float);
     static bool raised[MAX_DEVICES] = {};
-    if (lds > 64 * 1024 && !raised[cur_device()]) {
+    if (!raised[cur_device()]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_pipe16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised[cur_device()] = true;
+    }
+    if (!a) return hipSuccess;
+    static int split_env = -1;
+    if (split_env < 0) { const char* e = getenv("T3_GEMM_PIPE_SPLIT"); split_env = e ? atoi(e) : 0; }
+    const int mgroups = (a->M + 15) / 16, gx = a->N / 32;
+    int gy = split_env > 0 ? split_env : std::max(1, 256 / gx);
+    while (gy > 1 && mgroups / gy < 2) --gy;
+    launch_k(gemm2_pipe16_kernel, dim3(gx, gy), dim3(1024), lds, s, *a);
+    return hipGetLastError();
+}
+template <int NT, int EPI>
+static hipError_t launch_gemm2_pipe(const GemmArgs* a, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * 4 * 8192 + (size_t)2 * 4 * NT * 1024 + (size_t)2 * 4 * 16 * sizeof(float);
+    auto kern = gemm2_pipe_kernel<NT, EPI>;
+    static bool raised[MAX_DEVICES] = {};
+    if (!raised[cur_device()]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         raised[cur_device()] = true;
     }
     if (!a) return hipSuccess;
-    const int gx = (a->N / 16 + 1) / 2, gy = ((a->M + 15) / 16 + MT - 1) / MT;
+    static int split_env = -1;
+    if (split_env < 0) { const char* e = getenv("T3_GEMM_PIPE_SPLIT"); split_env = e ? atoi(e) : 0; }
+    const int mgroups = (a->M + 15) / 16;
+    const int gx = (a->N / 16) / (EPI == EPI_SILU ? NT / 2 : NT);
+    int gy = split_env > 0 ? split_env : std::max(1, 256 / gx);    // workgroups per n-group: one workgroup per CU (gate/up 128 x 2, qkv 64 x 4)
+    while (gy > 1 && mgroups / gy < 2) --gy;
     launch_k(kern, dim3(gx, gy), dim3(512), lds, s, *a);
     return hipGetLastError();
 }
@@ -986,10 +1110,6 @@ static hipError_t launch_gemm2_norm(const GemmArgs* a, int epi, int mt, int nt, 
     if (epi == EPI_F32) { if (mt >= 2) T3_G2(EPI_F32, 2, 1); else T3_G2(EPI_F32, 1, 1); }
     if (epi == EPI_BF16) { if (mt >= 2) { T3_G2_NT(EPI_BF16, 2) } else { T3_G2_NT(EPI_BF16, 1) } }
     if (epi == EPI_SILU) {
-        // two (gate, up) pairs per workgroup: the first pair's epilogue under the second pair's weight stream (T3_GEMM_SPLIT_EPI=0: gemm2_kernel's one epilogue)
-        static int split = -1;
-        if (split < 0) { const char* e = getenv("T3_GEMM_SPLIT_EPI"); split = e ? atoi(e) : 1; }
-        if (split && nt == 4 && a && !a->row_index && a->N % 32 == 0 && a->packed_tiles == 0) return mt >= 2 ? launch_gemm2_split<2>(a, s) : launch_gemm2_split<1>(a, s);
         if (mt >= 2) { if (nt == 4) T3_G2(EPI_SILU, 2, 4); else T3_G2(EPI_SILU, 2, 2); }
         else { if (nt == 4) T3_G2(EPI_SILU, 1, 4); else T3_G2(EPI_SILU, 1, 2); }
     }
@@ -1003,7 +1123,11 @@ static hipError_t launch_gemm2_16(const GemmArgs* a, int epi, int kbs, hipStream
     if (epi == EPI_F32) return kbs == 2 ? launch_gemm2_t<1, 1, EPI_F32, 16, 2, false>(a, s) : launch_gemm2_t<1, 1, EPI_F32, 16, 8, false>(a, s);
     return hipErrorInvalidValue;
 }
-void gemm_refresh_switches() { const char* ev = getenv("T3_GEMM_SMALL_M"); g_gemm_small_m = ev ? atoi(ev) : 1; }
+void gemm_refresh_switches() {
+    auto rd = [](const char* name, int dflt) { const char* ev = getenv(name); return ev ? atoi(ev) : dflt; };
+    g_gemm_small_m = rd("T3_GEMM_SMALL_M", 1); g_gemm_pipe = rd("T3_GEMM_PIPE", 1);
+    g_gemm_head_2percu = rd("T3_GEMM_HEAD_2PERCU", 1); g_gemm_pipe_qkv_min = rd("T3_GEMM_PIPE_QKV_MIN_ROWS", 129);
+}
 hipError_t prepare_gemm2() {
     hipError_t e;
     for (int epi : {EPI_F32, EPI_BF16, EPI_SILU})
@@ -1014,13 +1138,14 @@ hipError_t prepare_gemm2() {
         for (int kbs : {2, 8})
             if ((e = launch_gemm2_16(nullptr, epi, kbs, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_av<2, 4, EPI_BF16, 4, 8, true, 8, 0>(nullptr, nullptr)) != hipSuccess) return e;
-    if ((e = launch_gemm2_split<1>(nullptr, nullptr)) != hipSuccess) return e;
-    if ((e = launch_gemm2_split<2>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_t<1, 1, EPI_F32, 4, 8, false>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_t<2, 1, EPI_F32, 4, 8, false>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<2, 1, EPI_BF16, 4, 8, true>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<2, 2, EPI_SILU, 4, 8, true>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<2, 4, EPI_SILU, 4, 8, true>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_pipe<4, EPI_SILU>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_pipe16(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_pipe<3, EPI_BF16>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 8, false>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<1, 2, EPI_RESID, 16, 2, false>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 2, false>(nullptr, nullptr)) != hipSuccess) return e;
@@ -1067,6 +1192,12 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             // (T3_GEMM_LOOP_NT=2: one pair)
             static int loop_nt = -1;
             if (loop_nt < 0) { const char* e = getenv("T3_GEMM_LOOP_NT"); loop_nt = e ? atoi(e) : 4; }
+            // pipelined through compute and epilogue waves (gemm2_pipe_kernel; T3_GEMM_PIPE=0: the serial walk of gemm2_loop_kernel)
+            const int pipe = g_gemm_pipe;
+            if (pipe == 2 && loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU) return launch_gemm2_pipe<4, EPI_SILU>(&a, s);     // 4 + 4 waves
+            if (pipe && loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU) return launch_gemm2_pipe16(&a, s);
+            // qkv the same way from T3_GEMM_PIPE_QKV_MIN_ROWS rows on (3 n-tiles per workgroup: 64 x 4 workgroups)
+            if (pipe && g_gemm_pipe_qkv_min > 0 && a.M >= g_gemm_pipe_qkv_min && !a.row_index && a.N % 48 == 0 && epi == EPI_BF16) return launch_gemm2_pipe<3, EPI_BF16>(&a, s);
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU && loop_nt == 4) return launch_gemm2_loop_t<2, 4, EPI_SILU, 4, 8, true>(&a, s);
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_SILU) return launch_gemm2_loop_t<2, 2, EPI_SILU, 4, 8, true>(&a, s);
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_BF16 && getenv("T3_GEMM_LOOP_QKV")) return launch_gemm2_loop_t<2, 1, EPI_BF16, 4, 8, true>(&a, s);
@@ -1090,9 +1221,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             if (force >= 1 && force <= 4 && (epi != EPI_SILU || force % 2 == 0) && ntiles % force == 0) nt = force;
             // a grid a little over one round of 2 x 4 workgroups (the speech head at 64 rows: 129 x 2 = 258): the 4-wave variant of that
             // form, two workgroups per CU, all of them resident at once (T3_GEMM_HEAD_2PERCU=0: the 2 x 3 form, 344 workgroups in 1.3 rounds)
-            static int two_per_cu = -1;
-            if (two_per_cu < 0) { const char* e = getenv("T3_GEMM_HEAD_2PERCU"); two_per_cu = e ? atoi(e) : 1; }
-            if (two_per_cu && force == 0 && epi == EPI_BF16 && mt == 2 && ntiles % 4 == 0 && partial_round(4))
+            const int two_per_cu = g_gemm_head_2percu;
+            if (two_per_cu && force == 0 && epi == EPI_BF16 && a.row_index && a.packed_tiles > 0 && mt == 2 && ntiles % 4 == 0 && partial_round(4))
                 return launch_gemm2_av<2, 4, EPI_BF16, 4, 8, true, 8, 0>(&a, s);
         }
         return launch_gemm2_norm(&a, epi, mt, nt, s);

@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "t3_create", "t3_destroy", "t3_last_error", "t3_load_tensor", "t3_finalize_weights", "t3_add_request",
     "t3_step", "t3_run_until_done", "t3_run_steps", "t3_num_unfinished", "t3_get_output", "t3_get_timing", "t3_release_request", "t3_abort_request", "t3_handoff_tokens", "t3_reserve_handoff", "t3_pop_finished", "t3_debug_embeddings", "t3k_handoff",
     "t3_clean_tokens", "t3_debug_logits", "t3_step_times", "t3_stats", "t3_reset_stats", "t3_set_profile", "t3_set_profile_kernel", "t3_kernel_ms",
-    "t3k_gemm", "t3k_norm_gemm", "t3k_head_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_decode_attention", "t3k_sample", "t3k_sample_support", "t3k_expf",
+    "t3k_gemm", "t3k_norm_gemm", "t3k_qkv_gemm", "t3k_head_gemm", "t3k_gemm_resid", "t3k_silu_mul_gemm", "t3k_rope_attention", "t3k_decode_attention", "t3k_sample", "t3k_sample_support", "t3k_expf",
     "t3_cond_create", "t3_cond_destroy", "t3_cond_last_error", "t3_cond_load_tensor", "t3_cond_encode", "t3_cond_emotion_row",
     "t3k_ce_layernorm", "t3k_ce_linear", "t3k_ce_attention", "t3k_set_prefill_rows", "t3k_set_prefill_wide_rows",
 ]
@@ -121,6 +121,7 @@ def load_library():
     L.t3k_gemm.argtypes = [vp, vp, i32, i32, i32, vp, i32, i32]
     L.t3k_norm_gemm.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32]
     L.t3k_head_gemm.argtypes = [vp, vp, vp, i32, vp, i32, vp]
+    L.t3k_qkv_gemm.argtypes = [vp, vp, vp, i32, vp]
     L.t3k_gemm_resid.argtypes = [vp, vp, i32, i32, i32, vp]
     L.t3k_silu_mul_gemm.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.t3k_rope_attention.argtypes = [vp, vp, vp, i32, i32, i32, vp]
@@ -368,6 +369,15 @@ def k_norm_gemm(h: torch.Tensor, ln_w: torch.Tensor, W: torch.Tensor, row_index=
     out = torch.empty(M, W.shape[0], dtype=torch.float32)
     _chk_k(load_library().t3k_norm_gemm(h.data_ptr(), ln_w.data_ptr(), W.data_ptr(), M, W.shape[0], out.data_ptr(),
                                         None if ri is None else ri.ctypes.data, h.shape[0]), "t3k_norm_gemm")
+    return out
+
+
+def k_qkv_gemm(h: torch.Tensor, ln_w: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    """The qkv projection as a step launches it (norm folded, bf16 out) -> [M, 3072] bf16"""
+    h, ln_w, W = _bf(h), _bf(ln_w), _bf(W)
+    assert tuple(W.shape) == (3072, C.HIDDEN)
+    out = torch.empty(h.shape[0], 3072, dtype=torch.bfloat16)
+    _chk_k(load_library().t3k_qkv_gemm(h.data_ptr(), ln_w.data_ptr(), W.data_ptr(), h.shape[0], out.data_ptr()), "t3k_qkv_gemm")
     return out
 
 

@@ -235,6 +235,8 @@ int t3k_gemm(const void* x_bf16 /*[M][K]*/, const void* w_bf16 /*[N][K]*/, int32
  * h [Mh][1024] bf16, row_index nullable (then M == Mh). */
 int t3k_norm_gemm(const void* h_bf16, const void* ln_w_bf16, const void* w_bf16 /*[N][1024]*/, int32_t M, int32_t N,
                   float* out_f32, const int32_t* row_index, int32_t Mh);
+/* the qkv projection as a step launches it (input RMSNorm folded): w [3072][1024] (q, k, v rows), out bf16 [M][3072] */
+int t3k_qkv_gemm(const void* h_bf16, const void* ln_w_bf16, const void* w_bf16, int32_t M, void* out_bf16);
 /* the speech head as a decode step launches it (final RMSNorm folded, rows gathered through row_index [M] into h [Mh][1024], t3.py:650-673
  * before the CFG): out bf16 [M][8208], columns >= 8194 unspecified */
 int t3k_head_gemm(const void* h_bf16, const void* ln_w_bf16, const void* w_bf16 /*[8194][1024]*/, int32_t M, const int32_t* row_index, int32_t Mh, void* out_bf16);

@@ -118,15 +118,37 @@ def test_gate_up_silu_bit_exact(E, oracle, M):
     assert_bit_equal(got, oracle.silu_mul(g, u), "silu(gate)*up with folded norm")
 
 
+@pytest.mark.parametrize("M", [81, 100, 129, 255, 256, 300, 447])
+@pytest.mark.parametrize("pipe", ["1", "2", "0"])
+def test_gate_up_pipelined_groups_bit_exact(E, oracle, M, pipe, monkeypatch):
+    """gate/up at the model's width from 81 rows on (decode steps of 41+ utterances, C4's 256 rows, mixed steps up to 447): gemm2_pipe_kernel
+    -- 16-row groups pipelined through compute waves (rows by LDS-DMA into a double-buffered swizzled image, weights stationary) and epilogue
+    waves, one barrier per group -- and the serial walk it replaces (T3_GEMM_PIPE=0) against the oracle.  Row counts leave ragged last
+    groups, odd group counts (uneven shares of the two workgroups of an n-group) and a single group for one of them."""
+    monkeypatch.setenv("T3_GEMM_PIPE", pipe)
+    if pipe != "1" and M not in (100, 256, 300):
+        pytest.skip("the replaced form is checked at two row counts")
+    Fd = 4096
+    h = rand_bf16(M, 1024, seed=M, scale=2.0); ln = (rand_bf16(1024, seed=8) + 1.0).to(torch.bfloat16)
+    Wg = rand_bf16(Fd, 1024, seed=2, scale=0.1); Wu = rand_bf16(Fd, 1024, seed=3, scale=0.1)
+    got = E.k_silu_mul_gemm(h, ln, Wg, Wu)
+    g = oracle.norm_gemm(h, ln, Wg).to(torch.bfloat16); u = oracle.norm_gemm(h, ln, Wu).to(torch.bfloat16)
+    assert_bit_equal(got, oracle.silu_mul(g, u), f"silu(gate)*up, F=4096, M={M}, pipe={pipe}")
+
+
+@pytest.mark.parametrize("M", [2, 64, 128, 129, 200, 256, 300, 703])
+def test_qkv_form_bit_exact(E, oracle, M):
+    """The qkv projection as a step launches it (bf16 out, 3072 columns): the one-shot forms up to 128 rows, gemm2_pipe_kernel<3, BF16>
+    (groups pipelined through compute and epilogue waves) from 129 rows up to the prefill schedule's threshold."""
+    h = rand_bf16(M, 1024, seed=M, scale=2.0); ln = (rand_bf16(1024, seed=9) + 1.0).to(torch.bfloat16); W = rand_bf16(3072, 1024, seed=21, scale=0.05)
+    assert_bit_equal(E.k_qkv_gemm(h, ln, W), oracle.norm_gemm(h, ln, W).to(torch.bfloat16), f"qkv form M={M}")
+
+
 @pytest.mark.parametrize("M", [17, 20, 32, 33, 63, 64])
-@pytest.mark.parametrize("split", ["1", "0"])
-def test_gate_up_two_pairs_per_workgroup_bit_exact(E, oracle, M, split, monkeypatch):
-    """gate/up at the model's width (F = 4096, two (gate, up) pairs per workgroup at 17-64 rows): gemm2_split_kernel -- the first pair's
-    epilogue by the epilogue waves under the second pair's weight stream, the second pair's at one output per thread -- and the one-epilogue
-    form it replaces (T3_GEMM_SPLIT_EPI=0) against the oracle; ragged row counts leave a partial m-tile / m-group."""
-    monkeypatch.setenv("T3_GEMM_SPLIT_EPI", split)
-    if split == "0" and M not in (20, 64):
-        pytest.skip("the replaced form is checked at one row count per instantiation")
+def test_gate_up_two_pairs_per_workgroup_bit_exact(E, oracle, M):
+    """gate/up at the model's width (F = 4096): at 17-64 rows a workgroup takes two (gate, up) pairs (gemm2_kernel<1 | 2, 4, EPI_SILU>, the
+    form C3's 64-row steps run); ragged row counts leave a partial m-tile / m-group."""
+    split = "-"
     Fd = 4096
     h = rand_bf16(M, 1024, seed=M, scale=2.0); ln = (rand_bf16(1024, seed=8) + 1.0).to(torch.bfloat16)
     Wg = rand_bf16(Fd, 1024, seed=2, scale=0.1); Wu = rand_bf16(Fd, 1024, seed=3, scale=0.1)
