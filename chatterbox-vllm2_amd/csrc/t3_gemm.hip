@@ -946,7 +946,153 @@ __global__ __launch_bounds__(256, WC == 4 ? 2 : (NSEG == 4 ? 4 : 3)) void pgemm_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pgemm2_kernel: the prefill schedule at 256 x 128 workgroup tiles (8 waves as 4 x 2, a wave tile of 64 rows x 64 columns = 4 x 4 MFMA
+// tiles), K staged 64 deep.  What bounds pgemm_kernel is what a CU can take in (L2 -> LDS, ~70 GB/s per CU, MI355X_MICROARCH.md "Indexed
+// rows"): a workgroup tile of BM x BN stages (BM + BN) x 64 B per 32-deep K step for BM x BN / 256 MFMAs, and at 128 x 64 (four workgroups
+// per CU, nothing shared between them) that is 384 B per MFMA against the ~116 B per MFMA a CU can take in at the full matrix rate:
+// a ceiling of ~30 % (measured: 26 % MFMA busy on gate/up at 8 178 rows).  256 x 128 stages 192 B per MFMA (ceiling ~60 %), reads an
+// LDS fragment for two MFMAs instead of 1.3, and meets half as many barriers per K.  MEASURED (round 4): the same time per launch as
+// pgemm_kernel within +-5 % except down_proj (-20 % at 8 178 rows): a stage iteration takes ~1.8 us for 0.2 us of MFMA time per wave --
+// one workgroup per CU with every wave both issuing DMA pieces (~150 cycles each) and computing, re-synchronised by a barrier per stage,
+// leaves the matrix pipe idle three quarters of the time whatever the tile.  What is missing is a loader / consumer split (the guide's
+// ring-gemm), not a bigger tile; launch_pgemm takes this kernel only where it measured faster.  Same numbers: per output one MFMA chain per segment
+// from +0 in ascending k, segments folded left to right in groups of four, groups left to right (two / three accumulator sets).
+// Stage = A image 256 rows x 128 B (XOR-swizzled through the DMA source address: 16-byte chunk ch of row r sits at position
+// ch ^ ((r >> 1) & 7), which makes the 16 lanes of every ds_read_b128 lane group hit 16 different bank slots) | 8 packed n-tiles x 2
+// k-blocks x 1 KiB.  Ring of 3 stages (144 KiB), filled by LDS-DMA two stages ahead, 6 pieces per wave and stage, counted vmcnt, raw barriers.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int NSEG, bool NORM>
+__global__ __launch_bounds__(512) void pgemm2_kernel(GemmArgs a, const float* rstd) {
+    constexpr int NS = 3, AHEAD = NS - 1, PP = 6;                 // ring stages; stages in flight; DMA pieces per wave and stage
+    constexpr int STAGE = 2048 + 1024;                            // uint4 per stage: A image 32 KiB | B 16 KiB
+    extern __shared__ __attribute__((aligned(16))) uint4 ring2[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                     // wave tile: rows 64 wm .., packed n-tiles 4 wn .. 4 wn + 3
+    const int KB = a.K >> 5, NST = KB >> 1;                      // 32-deep k-blocks; 64-deep stages
+    const int spseg = (KB / NSEG) >> 1;                          // stages per segment (segments are 64 or 256 deep: 1 or 4)
+    const int m0 = blockIdx.y * 256, nt0 = blockIdx.x * 8;
+    // DMA sources.  A: piece j (of 32) = image rows 8 j .. 8 j + 7; lane l fills position p = l & 7 of row 8 j + (l >> 3), i.e. fetches
+    // the row's chunk p ^ ((row >> 1) & 7): the 8 lanes of a row fetch one whole 128-byte line.  A wave takes pieces 4 wave .. 4 wave + 3.
+    // B: piece (tile u, k-block kk) = 1 KiB of the packed matrix as it lies; wave w takes tile w, both k-blocks.
+    const uint16_t* xsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * (4 * wave + j) + (lane >> 3);
+        int m = m0 + row; m = m < a.M ? m : a.M - 1;
+        xsrc[j] = a.X + (size_t)m * a.K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    }
+    const uint4* wsrc = a.Wp + ((size_t)(nt0 + wave) * KB) * 64 + lane;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring2;
+    auto issue = [&](int st) {
+        const unsigned base = lds0 + (unsigned)((st % NS) * STAGE * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(xsrc[j] + st * 64, base + (unsigned)((4 * wave + j) * 1024));
+        glds16(wsrc + (size_t)(2 * st) * 64, base + (unsigned)(2048 * 16 + (wave * 2) * 1024));
+        glds16(wsrc + (size_t)(2 * st + 1) * 64, base + (unsigned)(2048 * 16 + (wave * 2 + 1) * 1024));
+    };
+    f32x4 sg[4][4], gr[4][4], tot[4][NSEG > 4 ? 4 : 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sg[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f}; gr[i][u] = sg[i][u]; if (NSEG > 4) tot[i][u] = sg[i][u]; }
+#pragma unroll
+    for (int k0 = 0; k0 < AHEAD; ++k0) if (k0 < NST) issue(k0);
+    const int c = lane & 15, q = lane >> 4;
+    int kin = 0, seg = 0;
+    for (int st = 0; st < NST; ++st) {
+        // stage st has landed once every wave has seen its own six pieces of it (vmcnt retires in issue order; the pieces of the next
+        // stage may still fly).  lgkmcnt(0): this wave's fragment reads of the previous stage are back, so the buffer refilled below is
+        // free once every wave is past the barrier.  A raw barrier: __syncthreads() would drain the DMA queue.
+        if (st + 1 < NST) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PP) : "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint4* As = ring2 + (st % NS) * STAGE;
+        const uint4* Bs = As + 2048;
+        if (st + AHEAD < NST) issue(st + AHEAD);                 // into the buffer of stage st - 1: every wave is past its reads (barrier above)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int row = wm * 64 + i * 16 + c; af[i] = As[row * 8 + ((4 * kk + q) ^ ((row >> 1) & 7))]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bf[u] = Bs[((wn * 4 + u) * 2 + kk) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(bf[u]), sg[i][u], 0, 0, 0);
+        }
+        if (++kin == spseg) {                    // segment complete: fold it
+            const bool first_in_group = (seg & 3) == 0, last_in_group = (seg & 3) == 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gr[i][u][r] = first_in_group ? sg[i][u][r] : gr[i][u][r] + sg[i][u][r];
+                        if constexpr (NSEG > 4) { if (last_in_group) tot[i][u][r] = seg == 3 ? gr[i][u][r] : tot[i][u][r] + gr[i][u][r]; }
+                        sg[i][u][r] = 0.0f;
+                    }
+                }
+            kin = 0; ++seg;
+        }
+    }
+    // epilogue: D[row = 4 (lane >> 4) + r][col = lane & 15] of every 16 x 16 tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 64 + i * 16 + 4 * q + r;
+            if (m >= a.M) continue;
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { if constexpr (NSEG > 4) v[u] = tot[i][u][r]; else v[u] = gr[i][u][r]; }
+            if constexpr (NORM) {
+                const float rs = rstd[m];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = v[u] * rs;
+            }
+            if constexpr (EPI == EPI_SILU) {
+#pragma unroll
+                for (int u = 0; u < 4; u += 2) {                             // packed pair (gate, up) -> one output tile
+                    const int n = ((nt0 + wn * 4 + u) >> 1) * 16 + c;
+                    if (n < a.N) reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)silu_mul_bf(f2bf(v[u]), f2bf(v[u + 1]));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int n = (nt0 + wn * 4 + u) * 16 + c;
+                    if (n >= a.N) continue;
+                    if constexpr (EPI == EPI_F32) {
+                        reinterpret_cast<float*>(a.out)[(size_t)m * a.ldo + n] = v[u];
+                    } else {
+                        uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
+                        if constexpr (EPI == EPI_BF16) *op = (uint16_t)f2bf(v[u]);
+                        else *op = (uint16_t)f2bf(bf2f(*op) + rbf(v[u]));     // EPI_RESID: h = bf16(h + bf16(y))
+                    }
+                }
+            }
+        }
+    }
+}
+template <int EPI, int NSEG, bool NORM>
+static hipError_t launch_pgemm2_t(const GemmArgs* a, const float* rs, dim3 grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)3 * 3072 * 16;
+    auto kern = pgemm2_kernel<EPI, NSEG, NORM>;
+    static bool raised[MAX_DEVICES] = {};
+    if (!raised[cur_device()]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised[cur_device()] = true;
+    }
+    if (!a) return hipSuccess;
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, *a, rs);
+    return hipGetLastError();
+}
+
 static int g_pgemm_min_rows = -1, g_pgemm_wide_rows = -1;
+static int g_pgemm2_min_wgs = 192, g_pgemm2_all = 0;
 static int g_gemm_pipe = 1, g_gemm_head_2percu = 1, g_gemm_pipe_qkv_min = 129;      // T3_GEMM_PIPE / T3_GEMM_HEAD_2PERCU / T3_GEMM_PIPE_QKV_MIN_ROWS (measurement switches, re-read with the next one)
 static int g_gemm_small_m = 1;          // T3_GEMM_SMALL_M=0: the one-tile GEMMs issue every activation-row load (read again by every prepare_kernels call, i.e. per engine)
 void set_pgemm_min_rows(int rows) { g_pgemm_min_rows = rows; }
@@ -961,6 +1107,25 @@ static hipError_t launch_pgemm(const GemmArgs& a, int epi, hipStream_t s) {
     // 128 x 128 tiles for the 4-segment forms from 2048 rows on only with T3_PGEMM_WC=4 (or the parity tests' hook): measured at
     // 8 178 rows x 30 layers, a prefill step takes 18.35 ms with 128 x 64 tiles, 18.76 with 128 x 128 and a 3-stage ring, 19.07
     // with a 4-stage ring -- the two workgroups per CU that fit hide less latency than the four of the narrow form
+    // 256 x 128 tiles (pgemm2_kernel) where they still cover the chip (>= g_pgemm2_min_wgs workgroups; T3_PGEMM2_MIN_WGS, 0 = never) AND
+    // where they measured faster (tools/gemm_bench, us per launch at 1 024 | 2 048 | 8 178 rows, 128 x 64 -> 256 x 128, profiles/
+    // r04_l_prefill_pgemm2_vs_pgemm.txt): down 34.1 -> 34.1 | 54.6 -> 53.0 | 125.3 -> 100.5, gate/up 42.8 -> 38.7 | 70.8 -> 67.8 | 224.1 -> 236.4,
+    // qkv 23.4 | 34.5 -> 37.6 | 93.1 -> 97.4, o 11.5 | 24.8 | 56.7 -> 58.3: down_proj always, gate/up below 4 096 rows (T3_PGEMM2_ALL=1: every form)
+    const bool pg2_form = g_pgemm2_all || (nseg == 16 && a.K == F) || (epi == EPI_SILU && a.M < 4096);
+    if (pg2_form && g_pgemm2_min_wgs > 0 && ntiles % 8 == 0 && (a.K & 63) == 0 && (long)(ntiles / 8) * ((a.M + 255) / 256) >= g_pgemm2_min_wgs) {
+        const dim3 grid2(ntiles / 8, (a.M + 255) / 256);
+        if (norm) {
+            hipLaunchKernelGGL(row_rstd_kernel, dim3((a.M + 63) / 64), dim3(256), 0, s, a.X, a.rstd_scratch, a.M);
+            if (epi == EPI_BF16) return launch_pgemm2_t<EPI_BF16, 4, true>(&a, a.rstd_scratch, grid2, s);
+            if (epi == EPI_F32) return launch_pgemm2_t<EPI_F32, 4, true>(&a, a.rstd_scratch, grid2, s);
+            if (epi == EPI_SILU) return launch_pgemm2_t<EPI_SILU, 4, true>(&a, a.rstd_scratch, grid2, s);
+            return hipErrorNotSupported;
+        }
+        if (epi == EPI_RESID && nseg == 16) return launch_pgemm2_t<EPI_RESID, 16, false>(&a, nullptr, grid2, s);
+        if (epi == EPI_F32 && nseg == 16) return launch_pgemm2_t<EPI_F32, 16, false>(&a, nullptr, grid2, s);
+        if (epi == EPI_F32) return launch_pgemm2_t<EPI_F32, 4, false>(&a, nullptr, grid2, s);
+        return hipErrorNotSupported;
+    }
     static int wc_env = -1;
     if (wc_env < 0) { const char* e = getenv("T3_PGEMM_WC"); wc_env = e ? atoi(e) : 2; }
     const int wide_rows = g_pgemm_wide_rows >= 0 ? g_pgemm_wide_rows : 2048;          // 0 = never
@@ -1126,6 +1291,7 @@ static hipError_t launch_gemm2_16(const GemmArgs* a, int epi, int kbs, hipStream
 void gemm_refresh_switches() {
     auto rd = [](const char* name, int dflt) { const char* ev = getenv(name); return ev ? atoi(ev) : dflt; };
     g_gemm_small_m = rd("T3_GEMM_SMALL_M", 1); g_gemm_pipe = rd("T3_GEMM_PIPE", 1);
+    g_pgemm2_min_wgs = rd("T3_PGEMM2_MIN_WGS", 192); g_pgemm2_all = rd("T3_PGEMM2_ALL", 0);
     g_gemm_head_2percu = rd("T3_GEMM_HEAD_2PERCU", 1); g_gemm_pipe_qkv_min = rd("T3_GEMM_PIPE_QKV_MIN_ROWS", 129);
 }
 hipError_t prepare_gemm2() {
@@ -1145,6 +1311,12 @@ hipError_t prepare_gemm2() {
     if ((e = launch_gemm2_loop_t<2, 4, EPI_SILU, 4, 8, true>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_pipe<4, EPI_SILU>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_pipe16(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_pgemm2_t<EPI_BF16, 4, true>(nullptr, nullptr, dim3(), nullptr)) != hipSuccess) return e;
+    if ((e = launch_pgemm2_t<EPI_F32, 4, true>(nullptr, nullptr, dim3(), nullptr)) != hipSuccess) return e;
+    if ((e = launch_pgemm2_t<EPI_SILU, 4, true>(nullptr, nullptr, dim3(), nullptr)) != hipSuccess) return e;
+    if ((e = launch_pgemm2_t<EPI_RESID, 16, false>(nullptr, nullptr, dim3(), nullptr)) != hipSuccess) return e;
+    if ((e = launch_pgemm2_t<EPI_F32, 16, false>(nullptr, nullptr, dim3(), nullptr)) != hipSuccess) return e;
+    if ((e = launch_pgemm2_t<EPI_F32, 4, false>(nullptr, nullptr, dim3(), nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_pipe<3, EPI_BF16>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 8, false>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<1, 2, EPI_RESID, 16, 2, false>(nullptr, nullptr)) != hipSuccess) return e;

@@ -68,10 +68,24 @@ def test_norm_folded_gemm_bit_exact(E, oracle, M, N):
     assert (got.double() - ref).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M", [256, 257, 300, 515, 770])
+def test_prefill_256x128_tiles_bit_exact(E, oracle, M, monkeypatch):
+    """pgemm2_kernel (256 x 128 workgroup tiles, K staged 64 deep, 8 waves): every form of the prefill schedule against the same oracle
+    functions, ragged row counts (a last row tile with 1 ... 255 rows); T3_PGEMM2_MIN_WGS=1 takes it at these small sizes (the engine
+    switches to it where 192+ workgroups result)."""
+    monkeypatch.setenv("T3_PGEMM2_MIN_WGS", "1"); monkeypatch.setenv("T3_PGEMM2_ALL", "1")
+    E.k_set_prefill_rows(256, 0)
+    try:
+        _prefill_sized_checks(E, oracle, M)
+    finally:
+        E.k_set_prefill_rows(-1)
+
+
 @pytest.mark.parametrize("M,wide", [(256, 0), (300, 0), (515, 0), (256, 256), (300, 256), (515, 256)])
-def test_prefill_sized_gemms_bit_exact(E, oracle, M, wide):
+def test_prefill_sized_gemms_bit_exact(E, oracle, M, wide, monkeypatch):
     """The LDS-tiled prefill schedule (pgemm_kernel, 128 x 64 or 128 x 128 workgroup tiles, row statistic in its own pass) must
     not change the numbers: every form against the same oracle functions, ragged row counts."""
+    monkeypatch.setenv("T3_PGEMM2_MIN_WGS", "0")
     E.k_set_prefill_rows(256, wide)                        # the engine switches per form at 448-1600 rows; here the schedule is checked on small cases
     try:
         _prefill_sized_checks(E, oracle, M)
