@@ -472,7 +472,7 @@ __global__ __launch_bounds__(512) void gemm2_pipe_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// gemm2_pipe16_kernel: gate/up's pipelined form at 16 waves per workgroup.  In gemm2_pipe_kernel<4, EPI_SILU> the four epilogue waves set
+// gemm2_pipe16_kernel: gate/up from 49 rows on (four 16-row groups = two per workgroup: C3's 64-row steps included, round 4) at 16 waves per workgroup.  In gemm2_pipe_kernel<4, EPI_SILU> the four epilogue waves set
 // the pace: a group's 512 outputs at two per thread are ~215 dependent vector instructions per wave, ~1.0 us, against ~0.4 us of matrix
 // work (tools/gemm_bench: +4.2 us per 128 rows).  Epilogue waves are only as many as the registers allow, and a compute wave that holds
 // two pairs' weight tiles needs 197.  Here the two (gate, up) pairs go to two SETS of four compute waves (64 registers of weights each,
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(1024) void gemm2_pipe16_kernel(GemmArgs a) {
     constexpr int NS = 4, KBS = 8, AIMG = 16 * KBS * 64;                          // K segments; a segment's A image of one group: 16 rows x 512 B
     constexpr int NA = 3;                                                           // A buffers: a group's rows are asked for TWO groups ahead (an L2 round trip under load is about one group)
     constexpr int PFL = 2 * 256;                                                    // a compute wave's partials of one group: [gate | up][4][64] floats
-    // LDS: [3 buffers][4 segments] A image (96 KiB) | [2][2 pairs][4 segments] partials (32 KiB) | [2][4][16] row statistic
+    // LDS: [3 buffers][4 segments] A image (96 KiB) | [2][2 pairs][4 segments] partials (32 KiB) | [2][4][16] row statistic | 256 B prefetch dump
     extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* pbase = reinterpret_cast<float*>(lds2 + NA * NS * AIMG);
@@ -498,6 +498,13 @@ __global__ __launch_bounds__(1024) void gemm2_pipe16_kernel(GemmArgs a) {
         __builtin_amdgcn_s_barrier();                            // the first group's rows are in (compute waves only)
         for (int j = 0; j < ng; ++j) {
             __builtin_amdgcn_s_barrier();                        // group j's partials are complete
+            // PrefetchArgs (64-row decode steps: down_proj's weights into the L2 of the XCD that will read them): behind the FIRST group's
+            // barrier every weight tile of this workgroup has landed and only rows (L2) move until the launch ends
+            if (j == 0 && ((gridDim.x * gridDim.y) & 7) == 0) {
+                const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+                const unsigned dump = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(rbase + 2 * NS * 16);
+                prefetch_next_weights(a.pf, lin & 7, (lin >> 3) * 8 + (wave - 8), ((gridDim.x * gridDim.y) >> 3) * 8, lane, dump);
+            }
             gemm2_fold_silu<1, 1, 2, 1>(a, pbase + (size_t)((j & 1) * 2 + pair) * NS * PFL, PFL, rbase + (j & 1) * NS * 16, pair, te & 255, 256, g0 + j * gs);
         }
         return;
@@ -1093,7 +1100,7 @@ static hipError_t launch_pgemm2_t(const GemmArgs* a, const float* rs, dim3 grid,
 
 static int g_pgemm_min_rows = -1, g_pgemm_wide_rows = -1;
 static int g_pgemm2_min_wgs = 192, g_pgemm2_all = 0;
-static int g_gemm_pipe = 1, g_gemm_head_2percu = 1, g_gemm_pipe_qkv_min = 129;      // T3_GEMM_PIPE / T3_GEMM_HEAD_2PERCU / T3_GEMM_PIPE_QKV_MIN_ROWS (measurement switches, re-read with the next one)
+static int g_gemm_pipe = 1, g_gemm_head_2percu = 1, g_gemm_pipe_qkv_min = 129, g_gemm_pipe_min = 49;      // T3_GEMM_PIPE / T3_GEMM_HEAD_2PERCU / T3_GEMM_PIPE_QKV_MIN_ROWS (measurement switches, re-read with the next one)
 static int g_gemm_small_m = 1;          // T3_GEMM_SMALL_M=0: the one-tile GEMMs issue every activation-row load (read again by every prepare_kernels call, i.e. per engine)
 void set_pgemm_min_rows(int rows) { g_pgemm_min_rows = rows; }
 void set_pgemm_wide_rows(int rows) { g_pgemm_wide_rows = rows; }
@@ -1210,7 +1217,7 @@ static hipError_t launch_gemm2_t(const GemmArgs* a, hipStream_t s) {
     return launch_gemm2_av<MT, NT, EPI, NW, KBS, NORM, KBS>(a, s);
 }
 static hipError_t launch_gemm2_pipe16(const GemmArgs* a, hipStream_t s) {
-    constexpr size_t lds = (size_t)3 * 4 * 8192 + (size_t)2 * 2 * 4 * 2048 + (size_t)2 * 4 * 16 * sizeof(float);
+    constexpr size_t lds = (size_t)3 * 4 * 8192 + (size_t)2 * 2 * 4 * 2048 + (size_t)2 * 4 * 16 * sizeof(float) + 256;
     static bool raised[MAX_DEVICES] = {};
     if (!raised[cur_device()]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_pipe16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1292,7 +1299,7 @@ void gemm_refresh_switches() {
     auto rd = [](const char* name, int dflt) { const char* ev = getenv(name); return ev ? atoi(ev) : dflt; };
     g_gemm_small_m = rd("T3_GEMM_SMALL_M", 1); g_gemm_pipe = rd("T3_GEMM_PIPE", 1);
     g_pgemm2_min_wgs = rd("T3_PGEMM2_MIN_WGS", 192); g_pgemm2_all = rd("T3_PGEMM2_ALL", 0);
-    g_gemm_head_2percu = rd("T3_GEMM_HEAD_2PERCU", 1); g_gemm_pipe_qkv_min = rd("T3_GEMM_PIPE_QKV_MIN_ROWS", 129);
+    g_gemm_head_2percu = rd("T3_GEMM_HEAD_2PERCU", 1); g_gemm_pipe_qkv_min = rd("T3_GEMM_PIPE_QKV_MIN_ROWS", 129); g_gemm_pipe_min = rd("T3_GEMM_PIPE_MIN_ROWS", 49);
 }
 hipError_t prepare_gemm2() {
     hipError_t e;
@@ -1367,7 +1374,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             // pipelined through compute and epilogue waves (gemm2_pipe_kernel; T3_GEMM_PIPE=0: the serial walk of gemm2_loop_kernel)
             const int pipe = g_gemm_pipe;
             if (pipe == 2 && loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU) return launch_gemm2_pipe<4, EPI_SILU>(&a, s);     // 4 + 4 waves
-            if (pipe && loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU) return launch_gemm2_pipe16(&a, s);
+            if (pipe && g_gemm_pipe_min > 0 && a.M >= g_gemm_pipe_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU) return launch_gemm2_pipe16(&a, s);
             // qkv the same way from T3_GEMM_PIPE_QKV_MIN_ROWS rows on (3 n-tiles per workgroup: 64 x 4 workgroups)
             if (pipe && g_gemm_pipe_qkv_min > 0 && a.M >= g_gemm_pipe_qkv_min && !a.row_index && a.N % 48 == 0 && epi == EPI_BF16) return launch_gemm2_pipe<3, EPI_BF16>(&a, s);
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU && loop_nt == 4) return launch_gemm2_loop_t<2, 4, EPI_SILU, 4, 8, true>(&a, s);

@@ -1,4 +1,5 @@
-// Internal launcher interface between engine.cpp and t3_kernels.hip (not part of the C ABI).
+// Internal launcher interface between engine.cpp / kernel_abi.cpp and the kernel translation units t3_gemm.hip, t3_attention.hip,
+// t3_kernels.hip (not part of the C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
