@@ -617,7 +617,10 @@ static int launch_sample_phase(T3Engine* e, T3Engine::Group& g, const T3Engine::
     const int n_sel = sr.n_sel;
     if (n_sel <= 0) return T3_OK;
     // final RMSNorm folded into the speech-head GEMM, which gathers the sampled rows itself
-    { Prof p(e, K_HEAD, s); GemmArgs a{g.h, (const uint4*)e->head, 2 * n_sel, D, V, g.logits, VPAD, 4, 1, g.dm.sel_rows, HEAD_TILES}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16, 4, true), s)); }
+    // decode-only steps sample every row, in row order: the gather is the identity and the head reads its rows directly (no dependent index
+    // loads in front of the activation loads)
+    const int* sel_rows = (sr.n_prefill_rows == 0 && sr.M == 2 * n_sel) ? nullptr : g.dm.sel_rows;
+    { Prof p(e, K_HEAD, s); GemmArgs a{g.h, (const uint4*)e->head, 2 * n_sel, D, V, g.logits, VPAD, 4, 1, sel_rows, HEAD_TILES}; HIP_TRY(launch_gemm(a, EPI_BF16, choose_mt(2 * n_sel, VPAD / 16, 4, true), s)); }
     { Prof p(e, K_SAMPLE, s); SampleArgs sa{g.logits, VPAD, g.dm.sel, e->d_counts, e->d_sp, e->cfg.cfg_scale, g.dm.out_tok, e->d_dbg, n_sel, e->d_hist, e->cfg.max_model_len, e->zero_copy ? g.h_out_tok[buf] : nullptr}; HIP_TRY(launch_sampler(sa, s)); }
     return T3_OK;
 }

@@ -1376,7 +1376,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             if (pipe == 2 && loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU) return launch_gemm2_pipe<4, EPI_SILU>(&a, s);     // 4 + 4 waves
             if (pipe && g_gemm_pipe_min > 0 && a.M >= g_gemm_pipe_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU) return launch_gemm2_pipe16(&a, s);
             // qkv the same way from T3_GEMM_PIPE_QKV_MIN_ROWS rows on (3 n-tiles per workgroup: 64 x 4 workgroups)
-            if (pipe && g_gemm_pipe_qkv_min > 0 && a.M >= g_gemm_pipe_qkv_min && !a.row_index && a.N % 48 == 0 && epi == EPI_BF16) return launch_gemm2_pipe<3, EPI_BF16>(&a, s);
+            if (pipe && g_gemm_pipe_qkv_min > 0 && a.M >= g_gemm_pipe_qkv_min && !a.row_index && a.packed_tiles == 0 && a.N % 48 == 0 && epi == EPI_BF16) return launch_gemm2_pipe<3, EPI_BF16>(&a, s);
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU && loop_nt == 4) return launch_gemm2_loop_t<2, 4, EPI_SILU, 4, 8, true>(&a, s);
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_SILU) return launch_gemm2_loop_t<2, 2, EPI_SILU, 4, 8, true>(&a, s);
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_BF16 && getenv("T3_GEMM_LOOP_QKV")) return launch_gemm2_loop_t<2, 1, EPI_BF16, 4, 8, true>(&a, s);
@@ -1401,7 +1401,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             // a grid a little over one round of 2 x 4 workgroups (the speech head at 64 rows: 129 x 2 = 258): the 4-wave variant of that
             // form, two workgroups per CU, all of them resident at once (T3_GEMM_HEAD_2PERCU=0: the 2 x 3 form, 344 workgroups in 1.3 rounds)
             const int two_per_cu = g_gemm_head_2percu;
-            if (two_per_cu && force == 0 && epi == EPI_BF16 && a.row_index && a.packed_tiles > 0 && mt == 2 && ntiles % 4 == 0 && partial_round(4))
+            if (two_per_cu && force == 0 && epi == EPI_BF16 && a.packed_tiles > 0 && mt == 2 && ntiles % 4 == 0 && partial_round(4))
                 return launch_gemm2_av<2, 4, EPI_BF16, 4, 8, true, 8, 0>(&a, s);
         }
         return launch_gemm2_norm(&a, epi, mt, nt, s);
