@@ -779,6 +779,27 @@ __global__ __launch_bounds__(NW * 64) void gemm2_loop_kernel(GemmArgs a) {
 // of four (G = ((s0 + s1) + s2) + s3), groups folded left to right -- hence three accumulator sets (segment, group, total).
 // The row statistic of the NORM forms comes from row_rstd_kernel (the same MFMA chains as gemm2_kernel's own).
 // ------------------------------------------------------------------------------------------------
+// XCD-aware tile order of the prefill schedules (speed only: any order computes the same tiles).  Workgroup L = by * gx + bx of a launch
+// runs on XCD L % 8 (tools/xcd_probe.hip), each XCD has its own 4 MiB L2, and in plain row-major order the workgroups that share an
+// operand tile sit on DIFFERENT XCDs: at 8 178 rows down_proj's eight column tiles of a row tile went to the eight XCDs, every L2 streamed
+// all of A, and the launch pulled 562 MB over the fabric for 75 MB of operands (gate/up: 596 MB for 33.5; FETCH_SIZE,
+// profiles/r04_p_pmc_fetch_size_by_kernel.json).  The map gives an XCD
+//   * a block of gx / 8 column tiles and every row tile (wide outputs: gate/up, qkv) -- its weight columns stay resident in its L2, a row
+//     tile is fetched once per XCD and shared by the column workgroups that run side by side; or
+//   * whole row tiles, eight at a time dealt over the XCDs (narrow outputs: o, down) -- a row tile's column workgroups share its rows in
+//     one L2, the (small) weight matrix streams through every L2 once.
+__device__ __forceinline__ void pgemm_tile_map(int gx, int gy, int& tx, int& ty) {
+    const int L = blockIdx.y * gx + blockIdx.x, xcd = L & 7, slot = L >> 3;
+    tx = blockIdx.x; ty = blockIdx.y;
+    if ((gx & 7) == 0 && gx >= 24) {                         // column blocks (gx * gy is a multiple of 8)
+        const int cpx = gx >> 3;
+        tx = xcd * cpx + slot % cpx; ty = slot / cpx;
+    } else if (gx <= 16) {                                   // row tiles, in bands of eight; the rows beyond the last full band keep the plain order
+        const int band_rows = gy & ~7;
+        if (L < gx * band_rows) { tx = slot % gx; ty = (slot / gx) * 8 + xcd; }
+    }
+}
+
 __global__ __launch_bounds__(256) void row_rstd_kernel(const uint16_t* h, float* rstd, int rows) {
     // one wave per 16 rows: per segment of 256 k the wave multiplies its A fragments with themselves (one MFMA chain from +0,
     // ascending k) and keeps the diagonal; the four segment sums fold ((S0 + S1) + S2) + S3 -- gemm2_kernel's own statistic
@@ -832,7 +853,9 @@ __global__ __launch_bounds__(256, WC == 4 ? 2 : (NSEG == 4 ? 4 : 3)) void pgemm_
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 1, wc = wave & 1;                                   // wave tile: rows 64 wr .., packed n-tiles 2 wc, 2 wc + 1
     const int KB = a.K >> 5, kbs = KB / NSEG;
-    const int m0 = blockIdx.y * 128, nt0 = blockIdx.x * NTW;
+    int tile_x, tile_y;
+    pgemm_tile_map((int)gridDim.x, (int)gridDim.y, tile_x, tile_y);
+    const int m0 = tile_y * 128, nt0 = tile_x * NTW;
     // A image: 64-byte rows, so four rows share a 256-byte bank row and the 16 rows of a fragment read would hit 4 bank slots.
     // Chunk q of row r sits at position ((r >> 2) & 3) ^ T[q], T = {0, 3, 2, 1} (an involution): the 16 lanes of each hardware
     // lane group of ds_read_b128 then land on 16 different slots.  A DMA piece writes LDS linearly, so the permutation is applied
@@ -978,7 +1001,9 @@ __global__ __launch_bounds__(512) void pgemm2_kernel(GemmArgs a, const float* rs
     const int wm = wave >> 1, wn = wave & 1;                     // wave tile: rows 64 wm .., packed n-tiles 4 wn .. 4 wn + 3
     const int KB = a.K >> 5, NST = KB >> 1;                      // 32-deep k-blocks; 64-deep stages
     const int spseg = (KB / NSEG) >> 1;                          // stages per segment (segments are 64 or 256 deep: 1 or 4)
-    const int m0 = blockIdx.y * 256, nt0 = blockIdx.x * 8;
+    int tile_x, tile_y;
+    pgemm_tile_map((int)gridDim.x, (int)gridDim.y, tile_x, tile_y);
+    const int m0 = tile_y * 256, nt0 = tile_x * 8;
     // DMA sources.  A: piece j (of 32) = image rows 8 j .. 8 j + 7; lane l fills position p = l & 7 of row 8 j + (l >> 3), i.e. fetches
     // the row's chunk p ^ ((row >> 1) & 7): the 8 lanes of a row fetch one whole 128-byte line.  A wave takes pieces 4 wave .. 4 wave + 3.
     // B: piece (tile u, k-block kk) = 1 KiB of the packed matrix as it lies; wave w takes tile w, both k-blocks.
@@ -1015,7 +1040,12 @@ __global__ __launch_bounds__(512) void pgemm2_kernel(GemmArgs a, const float* rs
         __builtin_amdgcn_s_barrier();
         const uint4* As = ring2 + (st % NS) * STAGE;
         const uint4* Bs = As + 2048;
-        if (st + AHEAD < NST) issue(st + AHEAD);                 // into the buffer of stage st - 1: every wave is past its reads (barrier above)
+        // Issuing a stage's six DMA pieces costs a wave 0.24-0.40 us (the CU's load path takes 64 B per clock: 48 KiB per stage) and its 32 MFMAs
+        // 0.4-0.5 us (stamps, profiles/r04_r_pgemm2_stamps.txt); with every wave doing one after the other in the same order, the load path
+        // idles while the matrix pipes run and the other way round.  Waves w and w + 4 share a SIMD: the first four issue, then compute;
+        // the other four compute, then issue (into the buffer of stage st - 1: every wave is past its reads of it, barrier above).
+        const bool issue_first = wave < 4;
+        if (issue_first && st + AHEAD < NST) issue(st + AHEAD);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             uint4 af[4], bf[4];
@@ -1023,12 +1053,22 @@ __global__ __launch_bounds__(512) void pgemm2_kernel(GemmArgs a, const float* rs
             for (int i = 0; i < 4; ++i) { const int row = wm * 64 + i * 16 + c; af[i] = As[row * 8 + ((4 * kk + q) ^ ((row >> 1) & 7))]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) bf[u] = Bs[((wn * 4 + u) * 2 + kk) * 64 + lane];
+            if (kk == 0 && kin == 0) {            // a segment's chain starts from +0: the accumulator operand is a zero tuple, nothing is cleared
+                const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(bf[u]), sg[i][u], 0, 0, 0);
+                    for (int u = 0; u < 4; ++u)
+                        sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(bf[u]), zero, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(bf[u]), sg[i][u], 0, 0, 0);
+            }
         }
+        if (!issue_first && st + AHEAD < NST) issue(st + AHEAD);
         if (++kin == spseg) {                    // segment complete: fold it
             const bool first_in_group = (seg & 3) == 0, last_in_group = (seg & 3) == 3;
 #pragma unroll
@@ -1039,7 +1079,6 @@ __global__ __launch_bounds__(512) void pgemm2_kernel(GemmArgs a, const float* rs
                     for (int r = 0; r < 4; ++r) {
                         gr[i][u][r] = first_in_group ? sg[i][u][r] : gr[i][u][r] + sg[i][u][r];
                         if constexpr (NSEG > 4) { if (last_in_group) tot[i][u][r] = seg == 3 ? gr[i][u][r] : tot[i][u][r] + gr[i][u][r]; }
-                        sg[i][u][r] = 0.0f;
                     }
                 }
             kin = 0; ++seg;
@@ -1117,8 +1156,10 @@ static hipError_t launch_pgemm(const GemmArgs& a, int epi, hipStream_t s) {
     // 256 x 128 tiles (pgemm2_kernel) where they still cover the chip (>= g_pgemm2_min_wgs workgroups; T3_PGEMM2_MIN_WGS, 0 = never) AND
     // where they measured faster (tools/gemm_bench, us per launch at 1 024 | 2 048 | 8 178 rows, 128 x 64 -> 256 x 128, profiles/
     // r04_l_prefill_pgemm2_vs_pgemm.txt): down 34.1 -> 34.1 | 54.6 -> 53.0 | 125.3 -> 100.5, gate/up 42.8 -> 38.7 | 70.8 -> 67.8 | 224.1 -> 236.4,
-    // qkv 23.4 | 34.5 -> 37.6 | 93.1 -> 97.4, o 11.5 | 24.8 | 56.7 -> 58.3: down_proj always, gate/up below 4 096 rows (T3_PGEMM2_ALL=1: every form)
-    const bool pg2_form = g_pgemm2_all || (nseg == 16 && a.K == F) || (epi == EPI_SILU && a.M < 4096);
+    // qkv 23.4 | 34.5 -> 37.6 | 93.1 -> 97.4, o 11.5 | 24.8 | 56.7 -> 58.3.  With the XCD-aware tile order, the stage's DMA issue and MFMAs in
+    // antiphase between the wave halves and no accumulator clearing (profiles/r04_t_pgemm_xcd_map.txt, 8 178 rows): down 84.5 (128 x 64: 119.0),
+    // o 49.5 (54.5), gate/up 230 (201), qkv 93.3 (91.6): the 16-segment forms always, gate/up below 4 096 rows (T3_PGEMM2_ALL=1: every form)
+    const bool pg2_form = g_pgemm2_all || nseg == 16 || (epi == EPI_SILU && a.M < 4096);
     if (pg2_form && g_pgemm2_min_wgs > 0 && ntiles % 8 == 0 && (a.K & 63) == 0 && (long)(ntiles / 8) * ((a.M + 255) / 256) >= g_pgemm2_min_wgs) {
         const dim3 grid2(ntiles / 8, (a.M + 255) / 256);
         if (norm) {
