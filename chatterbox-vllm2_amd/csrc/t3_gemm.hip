@@ -800,6 +800,44 @@ __device__ __forceinline__ void pgemm_tile_map(int gx, int gy, int& tx, int& ty)
     }
 }
 
+// Epilogue of the prefill schedules.  Their MFMAs take the WEIGHT fragment as the row operand and the activation fragment as the column
+// operand (D = W X^T: per output the same products and the same sums -- the matrix instruction is symmetric in its two operands, and the
+// parity tests hold it to the oracle), so a lane holds FOUR CONSECUTIVE COLUMNS n = 4 (lane >> 4) + r of ONE row m = lane & 15 of every
+// 16 x 16 tile: one 8-byte (bf16) or 16-byte (fp32) store where the row-major orientation needed four 2-byte ones, and one rstd per tile row.
+// v = the tile's accumulators (EPI_SILU: vu = the up tile's); nt = packed n-tile (EPI_SILU: the gate tile of the pair); rs = rstd or 1.
+template <int EPI>
+__device__ __forceinline__ void pgemm_store4(const GemmArgs& a, int m, int nt, int q, f32x4 v, f32x4 vu, float rs) {
+    if (m >= a.M) return;
+    const int n0 = (EPI == EPI_SILU ? (nt >> 1) : nt) * 16 + 4 * q;
+    if (n0 >= a.N) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r] = v[r] * rs; if (EPI == EPI_SILU) vu[r] = vu[r] * rs; }      // (NORM forms; rs = 1 multiplies exactly)
+    const bool wide = n0 + 3 < a.N && (a.ldo & 3) == 0;
+    if constexpr (EPI == EPI_F32) {
+        float* op = reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n0;
+        if (wide) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        else { for (int r = 0; r < 4; ++r) if (n0 + r < a.N) op[r] = v[r]; }
+    } else {
+        uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n0;
+        uint32_t ob[4];
+        if constexpr (EPI == EPI_SILU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[r] = silu_mul_bf(f2bf(v[r]), f2bf(vu[r]));
+        } else if constexpr (EPI == EPI_BF16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[r] = f2bf(v[r]);
+        } else {                                                 // EPI_RESID: h = bf16(h + bf16(y))
+            uint32_t hw[4];
+            if (wide) { const uint2 h2 = *reinterpret_cast<const uint2*>(op); hw[0] = h2.x & 0xffffu; hw[1] = h2.x >> 16; hw[2] = h2.y & 0xffffu; hw[3] = h2.y >> 16; }
+            else { for (int r = 0; r < 4; ++r) hw[r] = n0 + r < a.N ? op[r] : 0u; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[r] = f2bf(bf2f((uint16_t)hw[r]) + rbf(v[r]));
+        }
+        if (wide) *reinterpret_cast<uint2*>(op) = make_uint2(ob[0] | (ob[1] << 16), ob[2] | (ob[3] << 16));
+        else { for (int r = 0; r < 4; ++r) if (n0 + r < a.N) op[r] = (uint16_t)ob[r]; }
+    }
+}
+
 __global__ __launch_bounds__(256) void row_rstd_kernel(const uint16_t* h, float* rstd, int rows) {
     // one wave per 16 rows: per segment of 256 k the wave multiplies its A fragments with themselves (one MFMA chain from +0,
     // ascending k) and keeps the diagonal; the four segment sums fold ((S0 + S1) + S2) + S3 -- gemm2_kernel's own statistic
@@ -919,7 +957,7 @@ __global__ __launch_bounds__(256, WC == 4 ? 2 : (NSEG == 4 ? 4 : 3)) void pgemm_
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int u = 0; u < WC; ++u)
-                sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(bf[u]), sg[i][u], 0, 0, 0);
+                sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(bf[u]), as_frag(af[i]), sg[i][u], 0, 0, 0);      // D = W X^T: see pgemm_store4
 #endif
         if (++kin == kbs) {                      // segment complete: fold it
             const bool first_in_group = (seg & 3) == 0, last_in_group = (seg & 3) == 3;
@@ -937,41 +975,17 @@ __global__ __launch_bounds__(256, WC == 4 ? 2 : (NSEG == 4 ? 4 : 3)) void pgemm_
             kin = 0; ++seg;
         }
     }
-    // epilogue: D[row = 4 (lane >> 4) + r][col = lane & 15] of every 16 x 16 tile
+    // epilogue: D[n = 4 (lane >> 4) + r][m = lane & 15] of every 16 x 16 tile (pgemm_store4)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+        float rs = 1.0f;
+        if constexpr (NORM) rs = rstd[m < a.M ? m : a.M - 1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wr * 64 + i * 16 + 4 * (lane >> 4) + r;
-            if (m >= a.M) continue;
-            float v[WC];
-#pragma unroll
-            for (int u = 0; u < WC; ++u) { if constexpr (NSEG > 4) v[u] = tot[i][u][r]; else v[u] = gr[i][u][r]; }
-            if constexpr (NORM) {
-                const float rs = rstd[m];
-#pragma unroll
-                for (int u = 0; u < WC; ++u) v[u] = v[u] * rs;
-            }
-            if constexpr (EPI == EPI_SILU) {
-#pragma unroll
-                for (int u = 0; u < WC; u += 2) {                             // packed pair (gate, up) -> one output tile
-                    const int n = ((nt0 + wc * WC + u) >> 1) * 16 + (lane & 15);
-                    if (n < a.N) reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)silu_mul_bf(f2bf(v[u]), f2bf(v[u + 1]));
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < WC; ++u) {
-                    const int n = (nt0 + wc * WC + u) * 16 + (lane & 15);
-                    if (n >= a.N) continue;
-                    if constexpr (EPI == EPI_F32) {
-                        reinterpret_cast<float*>(a.out)[(size_t)m * a.ldo + n] = v[u];
-                    } else {
-                        uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
-                        if constexpr (EPI == EPI_BF16) *op = (uint16_t)f2bf(v[u]);
-                        else *op = (uint16_t)f2bf(bf2f(*op) + rbf(v[u]));     // EPI_RESID: h = bf16(h + bf16(y))
-                    }
-                }
-            }
+        for (int u = 0; u < WC; u += (EPI == EPI_SILU ? 2 : 1)) {
+            f32x4 v, vu;
+            if constexpr (NSEG > 4) { v = tot[i][u]; vu = tot[i][EPI == EPI_SILU ? u + 1 : u]; } else { v = gr[i][u]; vu = gr[i][EPI == EPI_SILU ? u + 1 : u]; }
+            pgemm_store4<EPI>(a, m, nt0 + wc * WC + u, lane >> 4, v, vu, rs);
         }
     }
 }
@@ -1059,13 +1073,13 @@ __global__ __launch_bounds__(512) void pgemm2_kernel(GemmArgs a, const float* rs
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(bf[u]), zero, 0, 0, 0);
+                        sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(bf[u]), as_frag(af[i]), zero, 0, 0, 0);      // D = W X^T: see pgemm_store4
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af[i]), as_frag(bf[u]), sg[i][u], 0, 0, 0);
+                        sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(bf[u]), as_frag(af[i]), sg[i][u], 0, 0, 0);
             }
         }
         if (!issue_first && st + AHEAD < NST) issue(st + AHEAD);
@@ -1084,41 +1098,17 @@ __global__ __launch_bounds__(512) void pgemm2_kernel(GemmArgs a, const float* rs
             kin = 0; ++seg;
         }
     }
-    // epilogue: D[row = 4 (lane >> 4) + r][col = lane & 15] of every 16 x 16 tile
+    // epilogue: D[n = 4 (lane >> 4) + r][m = lane & 15] of every 16 x 16 tile (pgemm_store4)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + c;
+        float rs = 1.0f;
+        if constexpr (NORM) rs = rstd[m < a.M ? m : a.M - 1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * 64 + i * 16 + 4 * q + r;
-            if (m >= a.M) continue;
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { if constexpr (NSEG > 4) v[u] = tot[i][u][r]; else v[u] = gr[i][u][r]; }
-            if constexpr (NORM) {
-                const float rs = rstd[m];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = v[u] * rs;
-            }
-            if constexpr (EPI == EPI_SILU) {
-#pragma unroll
-                for (int u = 0; u < 4; u += 2) {                             // packed pair (gate, up) -> one output tile
-                    const int n = ((nt0 + wn * 4 + u) >> 1) * 16 + c;
-                    if (n < a.N) reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n] = (uint16_t)silu_mul_bf(f2bf(v[u]), f2bf(v[u + 1]));
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int n = (nt0 + wn * 4 + u) * 16 + c;
-                    if (n >= a.N) continue;
-                    if constexpr (EPI == EPI_F32) {
-                        reinterpret_cast<float*>(a.out)[(size_t)m * a.ldo + n] = v[u];
-                    } else {
-                        uint16_t* op = reinterpret_cast<uint16_t*>(a.out) + (size_t)m * a.ldo + n;
-                        if constexpr (EPI == EPI_BF16) *op = (uint16_t)f2bf(v[u]);
-                        else *op = (uint16_t)f2bf(bf2f(*op) + rbf(v[u]));     // EPI_RESID: h = bf16(h + bf16(y))
-                    }
-                }
-            }
+        for (int u = 0; u < 4; u += (EPI == EPI_SILU ? 2 : 1)) {
+            f32x4 v, vu;
+            if constexpr (NSEG > 4) { v = tot[i][u]; vu = tot[i][EPI == EPI_SILU ? u + 1 : u]; } else { v = gr[i][u]; vu = gr[i][EPI == EPI_SILU ? u + 1 : u]; }
+            pgemm_store4<EPI>(a, m, nt0 + wn * 4 + u, q, v, vu, rs);
         }
     }
 }
@@ -1150,9 +1140,7 @@ static hipError_t launch_pgemm(const GemmArgs& a, int epi, hipStream_t s) {
     const int nseg = a.nw == 16 ? 16 : 4;
     const int ntiles = (a.N + 15) / 16 * (epi == EPI_SILU ? 2 : 1);
     if (a.row_index || ntiles % 4 || a.K % (32 * nseg) || (norm && (!a.rstd_scratch || a.K != D))) return hipErrorNotSupported;
-    // 128 x 128 tiles for the 4-segment forms from 2048 rows on only with T3_PGEMM_WC=4 (or the parity tests' hook): measured at
-    // 8 178 rows x 30 layers, a prefill step takes 18.35 ms with 128 x 64 tiles, 18.76 with 128 x 128 and a 3-stage ring, 19.07
-    // with a 4-stage ring -- the two workgroups per CU that fit hide less latency than the four of the narrow form
+    // (round 2: 128 x 128 tiles measured slower than 128 x 64 in plain row-major tile order, 18.76 against 18.35 ms per 8 178-row step)
     // 256 x 128 tiles (pgemm2_kernel) where they still cover the chip (>= g_pgemm2_min_wgs workgroups; T3_PGEMM2_MIN_WGS, 0 = never) AND
     // where they measured faster (tools/gemm_bench, us per launch at 1 024 | 2 048 | 8 178 rows, 128 x 64 -> 256 x 128, profiles/
     // r04_l_prefill_pgemm2_vs_pgemm.txt): down 34.1 -> 34.1 | 54.6 -> 53.0 | 125.3 -> 100.5, gate/up 42.8 -> 38.7 | 70.8 -> 67.8 | 224.1 -> 236.4,
@@ -1174,10 +1162,12 @@ static hipError_t launch_pgemm(const GemmArgs& a, int epi, hipStream_t s) {
         if (epi == EPI_F32) return launch_pgemm2_t<EPI_F32, 4, false>(&a, nullptr, grid2, s);
         return hipErrorNotSupported;
     }
+    // 128 x 128 tiles for the 4-segment forms from 4 096 rows on (round 4, with the XCD-aware tile order: gate/up 204 -> 198 us, qkv 84.7 ->
+    // 79.8 at 8 178 rows, nothing at 2 048: profiles/r04_v_pgemm_128x128.txt); T3_PGEMM_WC=2: never, =4: from 2 048 rows
     static int wc_env = -1;
-    if (wc_env < 0) { const char* e = getenv("T3_PGEMM_WC"); wc_env = e ? atoi(e) : 2; }
-    const int wide_rows = g_pgemm_wide_rows >= 0 ? g_pgemm_wide_rows : 2048;          // 0 = never
-    const bool wide = (wc_env == 4 || g_pgemm_wide_rows > 0) && nseg == 4 && ntiles % 8 == 0 && wide_rows > 0 && a.M >= wide_rows;
+    if (wc_env < 0) { const char* e = getenv("T3_PGEMM_WC"); wc_env = e ? atoi(e) : 0; }
+    const int wide_rows = g_pgemm_wide_rows >= 0 ? g_pgemm_wide_rows : (wc_env == 4 ? 2048 : 4096);          // 0 = never
+    const bool wide = wc_env != 2 && nseg == 4 && ntiles % 8 == 0 && wide_rows > 0 && a.M >= wide_rows;
     const dim3 grid(ntiles / (wide ? 8 : 4), (a.M + 127) / 128);
 #define T3_PG(E, SEG, NRM, RS) do { if (wide) hipLaunchKernelGGL((pgemm_kernel<E, SEG, NRM, 4>), grid, dim3(256), 0, s, a, (const float*)(RS)); \
                                     else hipLaunchKernelGGL((pgemm_kernel<E, SEG, NRM, 2>), grid, dim3(256), 0, s, a, (const float*)(RS)); } while (0)
