@@ -1376,8 +1376,13 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
         // 24.9 | 25.8 at 384 rows, 30.6 | 28.6 at 512; qkv 16.8 | 22.0 at 512, 25.4 | 23.6 at 768; o 17.0 | 20.4 and down 34.1 | 46.5
         // at 1023: the 16-segment fold of a 128 x 64 tile is a fixed ~18 / ~40 us): -2 = these per-form switches.
         if (g_pgemm_min_rows == -1) { const char* e = getenv("T3_PGEMM_MIN_ROWS"); g_pgemm_min_rows = e ? atoi(e) : -2; }
+        // Round 4 (tools/gemm_bench sweeps, profiles/r04_x_schedule_thresholds_*.txt): with gate/up and qkv pipelined through compute and
+        // epilogue waves the weights-stationary forms hold their per-row cost far beyond the old switches -- gate/up 21.9 | 27.9 | 41.0 us at
+        // 545 | 800 | 1 280 rows against 32.8 | 34.6 | 58.8 on the LDS-tiled schedule (which also pays a row-statistic launch), level at 2 048
+        // (61.8 both); qkv level at ~1 100 (20.4 | 20.9 at 1 024, 24.3 | 23.5 at 1 280); o looped 13.2 | 19.9 at 1 280, level at 2 048; down
+        // level from 1 280 to 1 600.  The mixed steps of continuous batching (256 decode rows + a prompt: 300-1 100 rows) now stay on them.
         const int pg_min = g_pgemm_min_rows != -2 ? g_pgemm_min_rows
-                         : epi == EPI_SILU ? 448 : (nw == 4 ? (a.row_index ? 1024 : 704) : (a.K == D ? 1280 : 1600));
+                         : epi == EPI_SILU ? 2048 : (nw == 4 ? (a.row_index ? 1024 : 1152) : (a.K == D ? 2048 : 1600));
         if (pg_min > 0 && a.M >= pg_min) {
             const hipError_t pe = launch_pgemm(a, epi, s);
             if (pe != hipErrorNotSupported) return pe;

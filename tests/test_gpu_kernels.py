@@ -150,6 +150,23 @@ def test_gate_up_pipelined_groups_bit_exact(E, oracle, M, pipe, monkeypatch):
     assert_bit_equal(got, oracle.silu_mul(g, u), f"silu(gate)*up, F=4096, M={M}, pipe={pipe}")
 
 
+@pytest.mark.parametrize("M", [1100, 2047])
+def test_weights_stationary_forms_up_to_their_new_switches(E, oracle, M):
+    """Round 4 moved the switches to the LDS-tiled prefill schedule up (gate/up 448 -> 2 048 rows, qkv 704 -> 1 152, o 1 280 -> 2 048): the
+    pipelined / looped forms at the row counts of continuous batching's mixed steps and beyond, ragged (M % 16 != 0), against the oracle.
+    Narrower outputs than the model's keep the oracle affordable and give the launchers other workgroup splits (gate/up 32 n-groups x 8)."""
+    h = rand_bf16(M, 1024, seed=M, scale=2.0); ln = (rand_bf16(1024, seed=8) + 1.0).to(torch.bfloat16)
+    Wg = rand_bf16(1024, 1024, seed=2, scale=0.1); Wu = rand_bf16(1024, 1024, seed=3, scale=0.1)
+    g = oracle.norm_gemm(h, ln, Wg).to(torch.bfloat16); u = oracle.norm_gemm(h, ln, Wu).to(torch.bfloat16)
+    assert_bit_equal(E.k_silu_mul_gemm(h, ln, Wg, Wu), oracle.silu_mul(g, u), f"gate/up (pipelined) M={M}")
+    x = rand_bf16(M, 1024, seed=M + 1); Wo = rand_bf16(1024, 1024, seed=4, scale=0.05); res = rand_bf16(M, 1024, seed=5, scale=2.0)
+    y = oracle.gemm(x, Wo, 64).to(torch.bfloat16)
+    assert_bit_equal(E.k_gemm_resid(x, Wo, res), (res.float() + y.float()).to(torch.bfloat16), f"o form (looped) M={M}")
+    if M <= 1151:
+        W = rand_bf16(3072, 1024, seed=21, scale=0.05)
+        assert_bit_equal(E.k_qkv_gemm(h, ln, W), oracle.norm_gemm(h, ln, W).to(torch.bfloat16), f"qkv form (pipelined) M={M}")
+
+
 @pytest.mark.parametrize("M", [2, 64, 128, 129, 200, 256, 300, 703])
 def test_qkv_form_bit_exact(E, oracle, M):
     """The qkv projection as a step launches it (bf16 out, 3072 columns): the one-shot forms up to 128 rows, gemm2_pipe_kernel<3, BF16>
