@@ -27,7 +27,8 @@ constexpr int KV_BLOCK_ELEMS = 2 * H * KV_HEAD_ELEMS;  // per layer per block: [
 enum GemmEpi { EPI_F32 = 0, EPI_BF16 = 1, EPI_RESID = 2, EPI_SILU = 3 };
 
 // Weights of a LATER launch on the stream, pulled into the L2 of the XCD that will read them while this launch leaves the memory system
-// idle: the fold + epilogue of a 4-wave GEMM form (0.4-1.3 us with nothing in flight).  The consumer is a gemm2_kernel whose workgroup bx
+// idle: the fold + epilogue of a 4-wave GEMM form (0.4-1.3 us with nothing in flight), or behind the first group's barrier of the pipelined
+// gate/up form (gemm2_pipe16_kernel: every weight tile has landed, only rows move).  The consumer is a gemm2_kernel whose workgroup bx
 // reads the `group` packed n-tiles bx * group ... (tile_lines 128-byte lines each, contiguous); block b of EVERY launch lands on XCD
 // (x0 + b) % 8 with the same x0 (tools/xcd_probe.hip: eager and graph launches, 1-D and 2-D grids of any size), so the lines of tile group g
 // are requested by workgroups of this launch whose linear id is g mod 8, one line per lane and instruction, by LDS-DMA into a 256-byte

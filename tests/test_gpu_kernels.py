@@ -177,8 +177,8 @@ def test_qkv_form_bit_exact(E, oracle, M):
 
 @pytest.mark.parametrize("M", [17, 20, 32, 33, 63, 64])
 def test_gate_up_two_pairs_per_workgroup_bit_exact(E, oracle, M):
-    """gate/up at the model's width (F = 4096): at 17-64 rows a workgroup takes two (gate, up) pairs (gemm2_kernel<1 | 2, 4, EPI_SILU>, the
-    form C3's 64-row steps run); ragged row counts leave a partial m-tile / m-group."""
+    """gate/up at the model's width (F = 4096) at 17-64 rows: two (gate, up) pairs per workgroup -- gemm2_kernel<1, 4, EPI_SILU> up to 48 rows,
+    gemm2_pipe16_kernel from 49 (the form C3's 64-row steps run); ragged row counts leave a partial m-tile / a single group for one workgroup."""
     split = "-"
     Fd = 4096
     h = rand_bf16(M, 1024, seed=M, scale=2.0); ln = (rand_bf16(1024, seed=8) + 1.0).to(torch.bfloat16)
