@@ -78,7 +78,7 @@ T_C2 = 108                        # C1 / C2: the 20-word English sentence under 
 
 
 def longest_prompt(args):
-    return T_C2 if args.workload == "c2" else T_ES
+    return T_C2 if getattr(args, "workload", "c3") == "c2" else T_ES
 
 
 def plan_window(args):
@@ -93,7 +93,7 @@ def plan_window(args):
 
 
 def workload_string(args, first, last):
-    if args.workload == "c2":
+    if getattr(args, "workload", "c3") == "c2":
         tag = "C2" if (args.max_model_len, args.layers) == (400, 30) else "custom (NOT a BASELINE.json config)"
         return (f"{tag}: t3-model (English, {args.layers}-layer Llama_520M, vocab 704), batch 1 (the 20-word sentence of C1, T={T_C2}), "
                 f"max_model_len={args.max_model_len} -> G={args.max_model_len - T_C2} tokens, CFG dual stream (2 rows/step), temperature 0.8 / top-p 0.8 / "

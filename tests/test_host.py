@@ -189,6 +189,7 @@ def test_bench_window_is_centred_and_self_launching(monkeypatch, capsys):
         seen["cmd"] = cmd
         return types.SimpleNamespace(returncode=0, stdout='noise\n{"metric": "m", "value": 1}\n')
     monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setenv("T3_BENCH_BACKEND", "gloo")          # (under nccl, more ranks than GPUs is refused before anything is started: tests/test_bench_host.py)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
     with pytest.raises(SystemExit) as ex:
         bench.spawn_ranks(types.SimpleNamespace(gpus=4))
