@@ -135,7 +135,9 @@ struct T3Engine {
     std::vector<Group> groups;
     unsigned step_seq = 0;
     bool run_ahead = true;     // t3_run_steps / t3_run_until_done enqueue step N+1 before reading step N's tokens
+    std::vector<Request*> dec_order;      // scratch of build_step
     int burst = BURST_MAX;     // T3_STEPS_PER_GRAPH: decode steps per graph replay in the run loops (1 = one step per replay)
+    bool longest_first = true; // T3_LONGEST_FIRST=0: decode rows in admission order instead of longest context first
     int64_t graph_captures = 0; double graph_capture_ms = 0;      // T3_GRAPH_STATS=1 prints them at destroy
     std::chrono::steady_clock::time_point t_last_complete{};
     std::vector<float> step_ms_ring = std::vector<float>(16384, 0.0f);   // t3_step_times: duration of the most recent steps (as accounted in gpu_ms_total)
@@ -219,6 +221,7 @@ extern "C" int t3_create(const T3EngineConfig* cfg, T3Handle* out) {
         if (const char* ev = getenv("T3_PREFETCH_DOWN_LINES")) e->prefetch_down_lines = atoi(ev);
         if (const char* ev = getenv("T3_RUN_AHEAD")) e->run_ahead = atoi(ev) != 0;
         if (const char* ev = getenv("T3_STEPS_PER_GRAPH")) e->burst = std::max(1, std::min(atoi(ev), (int)T3Engine::BURST_MAX));
+        if (const char* ev = getenv("T3_LONGEST_FIRST")) e->longest_first = atoi(ev) != 0;
     }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail_create(T3_E_DEVICE, "hipStreamCreate failed"); }
     hipEventCreate(&e->ev0); hipEventCreate(&e->ev1); hipEventCreateWithFlags(&e->ev_admit, hipEventDisableTiming);
@@ -651,10 +654,21 @@ static int build_step(T3Engine* e, T3Engine::Step& st, bool may_admit) {
         memcpy(rec + ROW_HDR, &e->h_block_table[(size_t)stream * e->max_blocks], (size_t)e->max_blocks * 4);
         ++sr.M;
     };
-    // decode rows of every running utterance, then prefill rows within the group's budget
+    // decode rows of every running utterance, then prefill rows within the group's budget.  Longest context first: the fused attention's
+    // workgroups (one per row and head, dispatched in row order) take a time proportional to the row's context, and a long row handed out
+    // last is a tail the rest of the chip waits for.  (Every context grows by one per step: the order only changes when the row set does.)
+    std::vector<Request*>& dec = e->dec_order;
+    dec.clear();
     for (int64_t id : e->running) {
         Request& r = e->reqs[id];
         if (r.state != DECODE || r.n_sched >= r.limit) continue;       // limit reached: its last token is in flight
+        dec.push_back(&r);
+    }
+    if (e->longest_first)
+        std::stable_sort(dec.begin(), dec.end(), [](const Request* x, const Request* y) {
+            return (int)x->prompt.size() + x->n_sched > (int)y->prompt.size() + y->n_sched; });
+    for (Request* rp : dec) {
+        Request& r = *rp;
         const int gi = r.slot % e->n_groups;
         T3Engine::StepRec& sr = st.g[gi];
         auto& hm = e->groups[gi].hm[buf];
