@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void attention_kernel(Att
     // rows (4-wave form) the same order is 0.6 % SLOWER (the launch streams at the memory system's pace from its first microsecond; 21.18 ->
     // 21.06 k tok/s, three alternating runs): the 4-wave form keeps the order of round 2.
     constexpr bool EARLY = FUSE && NW == 8;
-    const int lane = threadIdx.x & 63, wave = EARLY ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* sbuf = part + 66 * a.max_chunks + wave * 96;            // 64 floats of scores, then 64 bf16 (32 floats) of probabilities
     uint32_t* stash = reinterpret_cast<uint32_t*>(part + 66 * a.max_chunks + NW * 96) + wave * (12 * 64) + (threadIdx.x & 63);   // FUSE: the newest key / value park here
     uint16_t* pbuf = reinterpret_cast<uint16_t*>(sbuf + 64);

@@ -77,7 +77,7 @@ hipError_t launch_embed(const EmbedArgs& a, hipStream_t s) {
 constexpr int SWV = T3_SAMPLER_WAVES, STH = SWV * 64;
 constexpr int SPT = (8194 + STH - 1) / STH;     // elements per thread in contiguous ownership: STH * SPT >= 8194 (33 at 4 waves, 9 at 16)
 constexpr int SLOTS = STH * SPT;
-constexpr int SSCR = 32;                        // scratch words behind the weights: [SWV] wave partials | [24] the drawn token
+constexpr int SSCR = 32 + 5 * SWV + 4;          // reduction words behind the logits: [32] the two-barrier helpers' | five single-use arrays of [SWV] | [4] a radix round's result
 
 // Wave-level reductions and scans on the DPP cross-lane path (a ds_bpermute butterfly costs ~0.2 us per level here;
 // the sampler is a chain of such reductions).  All operands are integers (or a float max), so order is immaterial.
@@ -150,6 +150,34 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
     return v + before;
 }
 
+// Combining the SWV (<= 16) per-wave words of a reduction: lane w reads wave w's word and the row of 16 lanes folds them on the DPP path
+// (~20 instructions; a loop over the words was ~6 per word, and the sampler's sixteen waves are bound by instruction issue -- four waves
+// per SIMD, every instruction of "all waves" costs 16 cycles).  Call with all lanes active.
+__device__ __forceinline__ unsigned long long waves_sum_u64(const unsigned long long* arr, int lane) {
+    unsigned long long v = lane < SWV ? arr[lane] : 0;
+    v += dpp_u64<DPP_XOR1>(v); v += dpp_u64<DPP_XOR2>(v); v += dpp_u64<DPP_HALF_MIRROR>(v); v += dpp_u64<DPP_MIRROR>(v);
+    return readlane_u64(v, 0);
+}
+__device__ __forceinline__ unsigned long long waves_max_u64(const unsigned long long* arr, int lane) {
+    unsigned long long v = lane < SWV ? arr[lane] : 0;
+    v = max_u64(v, dpp_u64<DPP_XOR1>(v)); v = max_u64(v, dpp_u64<DPP_XOR2>(v));
+    v = max_u64(v, dpp_u64<DPP_HALF_MIRROR>(v)); v = max_u64(v, dpp_u64<DPP_MIRROR>(v));
+    return readlane_u64(v, 0);
+}
+// arr[w] = inclusive total of wave w's own scan: returns the sum over the waves before `wave`; *total = the sum over all
+__device__ __forceinline__ unsigned long long waves_before_u64(const unsigned long long* arr, int lane, int wave, unsigned long long* total) {
+    const unsigned long long own = lane < SWV ? arr[lane] : 0;
+    unsigned long long v = own;
+    v += dpp_u64<DPP_SHR + 1>(v); v += dpp_u64<DPP_SHR + 2>(v); v += dpp_u64<DPP_SHR + 4>(v); v += dpp_u64<DPP_SHR + 8>(v);      // inclusive within the row of 16
+    *total = readlane_u64(v, 15);
+    return readlane_u64(v - own, wave);
+}
+
+__device__ __forceinline__ uint32_t t3_cvt_u32_trunc(float f) {      // v_cvt_u32_f32: truncation toward zero, NaN -> 0 (callers pass 0 <= f < 2^32 or NaN)
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
 __device__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -172,233 +200,328 @@ __global__ __launch_bounds__(STH) void sampler_kernel(SampleArgs a) {
     unsigned long long clk[12] = {0};
 #endif
     T3_CLK(0);
-    extern __shared__ __attribute__((aligned(16))) unsigned long long sw[];   // [SLOTS] weights | [SSCR] scratch | [256] histogram copies
-    unsigned long long* scr = sw + SLOTS;
+    // LDS: [SLOTS] x (fp32) | [SSCR] reduction words | 3 x [2][HC][64] histogram copies (mass + count, smallest, largest).  Every reduction of the sampled path has words of its
+    // own, so it is write -> ONE barrier -> read (round 3 shared one scratch array: two barriers per reduction, 35 barriers per launch
+    // for sixteen waves; tools/sampler_clk.py, profiles/NOTES.md).
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sw[];
+    float* xs = reinterpret_cast<float*>(sw);
+    unsigned long long* scr = sw + SLOTS / 2;              // legacy two-barrier helpers (greedy, min-p / top-k, degenerate top-p): [SWV] + [24..25]
+    unsigned long long* s_mx = scr + 32;                   // [SWV] max of the scaled logits
+    unsigned long long* s_wm = s_mx + SWV;                 // [SWV] largest weight
+    unsigned long long* s_ws = s_wm + SWV;                 // [SWV] sum of the weights
+    unsigned long long* s_ti = s_ws + SWV;                 // [SWV] ties scan
+    unsigned long long* s_dr = s_ti + SWV;                 // [SWV] draw scan
     unsigned long long* psum = scr + SSCR;
-    const int tid = threadIdx.x, u = blockIdx.x;
+    const int tid = threadIdx.x, u = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = a.sel[u].x;
     const uint32_t step = (uint32_t)a.sel[u].y;
     const T3Sampling sp = a.sp[slot];
     const uint16_t* lc = a.logits + (size_t)(2 * u) * a.ldl;
     const uint16_t* lu = lc + a.ldl;
     uint16_t* counts = a.counts + (size_t)slot * VPAD;
-    float* xs = reinterpret_cast<float*>(sw);     // phase A: xs[v] (fp32) lives in the low half of slot v
 
-    // ---- phase A: CFG, penalties.  16-byte loads of 8 logits / counts, all issued before the first use
-    // (a scalar loop here is a chain of dependent memory latencies, not bandwidth).
-    const bool greedy = sp.temperature < 1e-5f;
-    float mx = -INFINITY;
-    unsigned long long best = 0;
-    constexpr int NVEC = VPAD / 8, VIT = (NVEC + STH - 1) / STH;
-    static_assert(VPAD % 8 == 0 && SLOTS >= VPAD, "sampler vector layout");
-    uint4 c4[VIT], u4[VIT], n4[VIT];
-#pragma unroll
-    for (int k = 0; k < VIT; ++k) {
-        const int vi = tid + STH * k;
-        if (vi < NVEC) {
-            c4[k] = reinterpret_cast<const uint4*>(lc)[vi];
-            u4[k] = reinterpret_cast<const uint4*>(lu)[vi];
-            n4[k] = reinterpret_cast<const uint4*>(counts)[vi];
-        }
-    }
-    for (int v = VPAD + tid; v < SLOTS; v += STH) xs[2 * v] = -INFINITY;
-    T3_CLK(1);
-#pragma unroll
-    for (int k = 0; k < VIT; ++k) {
-        const int vi = tid + STH * k;
-        if (vi >= NVEC) continue;
-        const uint32_t cw[4] = {c4[k].x, c4[k].y, c4[k].z, c4[k].w}, uw[4] = {u4[k].x, u4[k].y, u4[k].z, u4[k].w},
-                       nw[4] = {n4[k].x, n4[k].y, n4[k].z, n4[k].w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int v = vi * 8 + j;
-            const int sh = (j & 1) * 16;
-            float x = -INFINITY;
-            if (v < V) {
-                const float c = bf2f((uint16_t)(cw[j >> 1] >> sh)), un = bf2f((uint16_t)(uw[j >> 1] >> sh));
-                const float d = rbf(c - un);
-                const float e = rbf(a.cfg * d);
-                x = rbf(c + e);
-                if (a.dbg) a.dbg[(size_t)slot * V + v] = x;
-                const uint32_t cnt = (nw[j >> 1] >> sh) & 0xFFFFu;
-                if (cnt > 0) {
-                    if (sp.repetition_penalty != 1.0f) x = (x > 0.0f) ? x / sp.repetition_penalty : x * sp.repetition_penalty;
-                    x = x - sp.frequency_penalty * (float)cnt;
-                    x = x - sp.presence_penalty;
-                }
-                if (greedy) {
-                    const float xz = x + 0.0f;                       // -0 -> +0 so that the key order equals '>' on floats
-                    uint32_t b = __float_as_uint(xz);
-                    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-                    const unsigned long long key = ((unsigned long long)b << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)v);
-                    best = key > best ? key : best;
-                } else {
-                    x = x / sp.temperature;
-                    mx = fmaxf(mx, x);
-                }
-            }
-            xs[2 * v] = x;
-        }
-    }
-    T3_CLK(2);
-    int token;
-    if (greedy) {
-        best = block_max_u64(best, scr);
-        token = (int)(0xFFFFFFFFu - (uint32_t)best);
-    } else {
-        mx = block_max_f32(mx, scr);
-        // ---- weights (block_max above is the barrier between writing xs and overwriting it slot by slot)
-#pragma unroll
-        for (int k = 0; k < SPT; ++k) {
-            const int v = tid + STH * k;
-            const float x = xs[2 * v];
-            unsigned long long w = 0;
-            if (v < V) w = (unsigned long long)(t3_expf(x - mx) * 4294967296.0f);
-            sw[v] = w;
-        }
-        __syncthreads();
-        T3_CLK(3);
-        // From here on a thread owns SPT consecutive vocabulary entries and keeps them in registers.
-        const int v0 = tid * SPT;
-        unsigned long long wr[SPT];
-#pragma unroll
-        for (int i = 0; i < SPT; ++i) wr[i] = sw[v0 + i];
-        unsigned long long wmax = 0;
-#pragma unroll
-        for (int i = 0; i < SPT; ++i) wmax = max_u64(wmax, wr[i]);
-        wmax = block_max_u64(wmax, scr);
-        if (sp.min_p > 0.0f) {
-            const double thr = (double)sp.min_p * (double)wmax;
-#pragma unroll
-            for (int i = 0; i < SPT; ++i) if ((double)wr[i] < thr) wr[i] = 0;
-        }
-        if (sp.top_k > 0 && sp.top_k < V) {
-            unsigned long long lo = 0, hi = wmax;
-            while (lo < hi) {
-                const unsigned long long mid = lo + (hi - lo + 1) / 2;
-                unsigned long long cnt = 0;
-#pragma unroll
-                for (int i = 0; i < SPT; ++i) cnt += (wr[i] >= mid) ? 1 : 0;
-                cnt = block_sum_u64(cnt, scr);
-                if (cnt >= (unsigned long long)sp.top_k) lo = mid; else hi = mid - 1;
-            }
-#pragma unroll
-            for (int i = 0; i < SPT; ++i) if (wr[i] < lo) wr[i] = 0;
-        }
-        T3_CLK(4);
-        if (sp.top_p < 1.0f) {
-            unsigned long long W = 0;
-#pragma unroll
-            for (int i = 0; i < SPT; ++i) W += wr[i];
-            W = block_sum_u64(W, scr);
-            const unsigned long long Tm = (unsigned long long)((1.0 - (double)sp.top_p) * (double)W);
-            // lo = max{mid : sum of weights < mid is <= Tm} is the weight value at which the ascending cumulative
-            // mass first exceeds Tm.  Radix descent on the value: one round over the octaves, then 6 bits per
-            // round; per round an LDS histogram of masses (exact integer sums, so order-free) and a 64-bin
-            // wave scan that every wave repeats for itself.
-            T3_CLK(5);
-            // The histogram is kept in HC copies, one per lane group (lane & (HC - 1)): the masses of a round fall into a handful of the 64
-            // bins (a softmax's weights share few octaves), and 64-bit LDS atomics of one wave instruction onto the same bin serialise.  The sums
-            // are exact integers, so the copies add up to the same histogram in any order.
-            constexpr int HC = 4;
-            unsigned long long* hist = psum;                 // [HC][64]
-            const int lane = tid & 63;
-            unsigned long long* myhist = hist + (lane & (HC - 1)) * 64;
-            unsigned long long lo = wmax, base = 0, prefix = 0;
-            int nb = -1;                                     // bits of the value still undetermined; -1: octave round
-            for (;;) {
-                __syncthreads();
-                if (tid < HC * 64) hist[tid] = 0;
-                __syncthreads();
-                if (nb < 0) {
-#pragma unroll
-                    for (int i = 0; i < SPT; ++i) if (wr[i]) atomicAdd(&myhist[64 - __clzll((long long)wr[i])], wr[i]);
-                } else {
-                    const int shift = nb > 6 ? nb - 6 : 0;
-                    const unsigned long long msk = (1ull << (nb - shift)) - 1;
-#pragma unroll
-                    for (int i = 0; i < SPT; ++i) if ((wr[i] >> nb) == prefix) atomicAdd(&myhist[(wr[i] >> shift) & msk], wr[i]);
-                }
-                __syncthreads();
-                const unsigned long long own = (hist[lane] + hist[64 + lane]) + (hist[128 + lane] + hist[192 + lane]);
-                const unsigned long long c = wave_scan_u64(own, lane);      // inclusive scan over the 64 bins
-                const unsigned long long over = __ballot(base + c > Tm);
-                if (!over) break;                            // only in the octave round, when Tm == W: lo = wmax
-                const int b = __ffsll((long long)over) - 1;
-                base += readlane_u64(c - own, b);
-                if (nb < 0) { prefix = 1; nb = b - 1; }
-                else { const int shift = nb > 6 ? nb - 6 : 0; prefix = (prefix << (nb - shift)) | (unsigned long long)b; nb = shift; }
-                if (nb == 0) { lo = prefix; break; }
-            }
-            T3_CLK(6);
-            if (lo > 0) {
-                unsigned long long below = 0, my_ties = 0;
-#pragma unroll
-                for (int i = 0; i < SPT; ++i) { below += (wr[i] < lo) ? wr[i] : 0; my_ties += (wr[i] == lo) ? 1 : 0; }
-                below = block_sum_u64(below, scr);
-                unsigned long long ties;
-                const unsigned long long incl = block_scan_u64(my_ties, scr, &ties);
-                unsigned long long r = (Tm - below) / lo;
-                if (lo == wmax && r > ties - 1) r = ties - 1;
-                if (r > ties) r = ties;
-                // ties are dropped highest index first
-                unsigned long long above = ties - incl;          // ties owned by higher threads
-#pragma unroll
-                for (int i = SPT - 1; i >= 0; --i) {
-                    if (wr[i] < lo) wr[i] = 0;
-                    else if (wr[i] == lo) { if (above < r) wr[i] = 0; ++above; }
-                }
-            }
-        }
-        T3_CLK(7);
-        if (a.dbg_keep) {                                   // parity hook: the support of the draw (what the masks left)
-#pragma unroll
-            for (int i = 0; i < SPT; ++i) if (v0 + i < V) a.dbg_keep[(size_t)slot * V + v0 + i] = wr[i] != 0;
-        }
-        // ---- draw
-        unsigned long long mine = 0;
-#pragma unroll
-        for (int i = 0; i < SPT; ++i) mine += wr[i];
-        unsigned long long Wk;
-        const unsigned long long excl = block_scan_u64(mine, scr, &Wk) - mine;
-        T3_CLK(8);
-        uint32_t rnd[4];
-        philox4x32_10(step, (uint32_t)sp.uid, (uint32_t)(sp.uid >> 32), 0u, (uint32_t)sp.seed, (uint32_t)(sp.seed >> 32), rnd);
-        const unsigned long long uu = ((unsigned long long)rnd[1] << 32) | rnd[0];
-        const unsigned long long target = __umul64hi(uu, Wk);
-        int* tokp = reinterpret_cast<int*>(scr + 24);
-        // No thread owns the target when there is no mass at all (NaN logits: a checkpoint or conditioning with NaN / Inf makes
-        // every weight 0): the draw then falls back to the stop id instead of whatever the LDS word held.  The write is ordered
-        // before the owner's by the barriers inside block_scan_u64 above (scr + 24 is not one of its SWV words).
-        if (Wk == 0 && tid == 0) *tokp = (sp.stop_token >= 0 && sp.stop_token < V) ? sp.stop_token : 0;
-        if (mine > 0 && target >= excl && target < excl + mine) {
-            unsigned long long cum = excl; int found = -1;      // first entry whose running mass passes the target
-#pragma unroll
-            for (int i = 0; i < SPT; ++i) { cum += wr[i]; if (found < 0 && cum > target) found = v0 + i; }
-            *tokp = found;
-        }
-        __syncthreads();
-        token = *tokp;
-        T3_CLK(9);
-    }
-    if (tid == 0) {
+    // the drawn id leaves the kernel through whichever thread knows it
+    auto finish = [&](int token) {
         token = token < 0 ? 0 : (token >= V ? V - 1 : token);       // counts[] / speech_emb[] are indexed with it
-        if (a.dbg_keep && greedy) a.dbg_keep[(size_t)slot * V + token] = 1;      // (zeroed by the caller)
         a.out_tok[u] = token;
         if (a.out_tok_host) a.out_tok_host[u] = token;
         if (a.hist && (int)step < a.hist_cap) a.hist[(size_t)slot * a.hist_cap + step] = token;      // the utterance's ids stay on the device
         const uint16_t cnt = counts[token];
         if (cnt < 65535) counts[token] = cnt + 1;
 #ifdef T3_SAMPLER_CLK
-        if (a.dbg) for (int i = 0; i < 10; ++i) a.dbg[(size_t)slot * V + i] = (float)(clk[i] - clk[0]);
+        T3_CLK(10);
+        if (a.dbg) for (int i = 0; i < 11; ++i) a.dbg[(size_t)slot * V + i] = (float)(clk[i] - clk[0]);
 #endif
+    };
+
+    // ---- phase A: CFG, penalties.  16-byte loads of 8 logits / counts, all issued before the first use
+    // (a scalar loop here is a chain of dependent memory latencies, not bandwidth).
+    const bool greedy = sp.temperature < 1e-5f;
+    float mx = -INFINITY;
+    unsigned long long best = 0;
+    // 8 logits per 16-byte load: KF full rounds of STH vectors; the LV vectors left over (8 208 = 1 024 x 8 + 16: two of them hold the ids
+    // 8 192 and 8 193) go element by element to the lanes of the last wave -- as a second, nearly empty round of the unrolled vector
+    // loop they doubled wave 0's phase A (3 us) while fifteen waves waited at the barrier.
+    constexpr int NVEC = VPAD / 8, KF = NVEC / STH, LV = NVEC - KF * STH, TAIL0 = KF * STH * 8;
+    static_assert(VPAD % 8 == 0 && SLOTS >= VPAD && SLOTS % 2 == 0 && LV * 8 <= 64, "sampler vector layout");
+    uint4 c4[KF], u4[KF], n4[KF];
+#pragma unroll
+    for (int k = 0; k < KF; ++k) {
+        const int vi = tid + STH * k;
+        c4[k] = reinterpret_cast<const uint4*>(lc)[vi];
+        u4[k] = reinterpret_cast<const uint4*>(lu)[vi];
+        n4[k] = reinterpret_cast<const uint4*>(counts)[vi];
+    }
+    const bool tail = LV > 0 && wave == SWV - 1 && lane < LV * 8;
+    uint16_t tc = 0, tu = 0, tn = 0;
+    if (tail) { tc = lc[TAIL0 + lane]; tu = lu[TAIL0 + lane]; tn = counts[TAIL0 + lane]; }
+    for (int v = VPAD + tid; v < SLOTS; v += STH) xs[v] = -INFINITY;
+    constexpr int HC = 4, HSZ = HC * 64;                 // histogram copies (see the radix rounds), words per histogram
+    unsigned long long* hmin = psum + 2 * HSZ;           // [2][HC][64] smallest / largest entry of a bin (rounds behind the octave round)
+    unsigned long long* hmax = psum + 4 * HSZ;
+    for (int j = tid; j < 2 * HSZ; j += STH) { psum[j] = 0; hmin[j] = ~0ull; hmax[j] = 0; }
+    T3_CLK(1);
+    auto element = [&](uint16_t cb, uint16_t ub, uint32_t cnt, int v) -> float {
+        float x = -INFINITY;
+        if (v < V) {
+            const float c = bf2f(cb), un = bf2f(ub);
+            const float d = rbf(c - un);
+            const float e = rbf(a.cfg * d);
+            x = rbf(c + e);
+            if (a.dbg) a.dbg[(size_t)slot * V + v] = x;
+            if (cnt > 0) {
+                if (sp.repetition_penalty != 1.0f) x = (x > 0.0f) ? x / sp.repetition_penalty : x * sp.repetition_penalty;
+                x = x - sp.frequency_penalty * (float)cnt;
+                x = x - sp.presence_penalty;
+            }
+            if (greedy) {
+                const float xz = x + 0.0f;                       // -0 -> +0 so that the key order equals '>' on floats
+                uint32_t b = __float_as_uint(xz);
+                b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+                const unsigned long long key = ((unsigned long long)b << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)v);
+                best = key > best ? key : best;
+            } else {
+                x = x / sp.temperature;
+                mx = fmaxf(mx, x);
+            }
+        }
+        return x;
+    };
+#pragma unroll
+    for (int k = 0; k < KF; ++k) {
+        const int vi = tid + STH * k;
+        const uint32_t cw[4] = {c4[k].x, c4[k].y, c4[k].z, c4[k].w}, uw[4] = {u4[k].x, u4[k].y, u4[k].z, u4[k].w},
+                       nw[4] = {n4[k].x, n4[k].y, n4[k].z, n4[k].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int sh = (j & 1) * 16;
+            xs[vi * 8 + j] = element((uint16_t)(cw[j >> 1] >> sh), (uint16_t)(uw[j >> 1] >> sh), (nw[j >> 1] >> sh) & 0xFFFFu, vi * 8 + j);
+        }
+    }
+    if (tail) xs[TAIL0 + lane] = element(tc, tu, tn, TAIL0 + lane);
+    T3_CLK(2);
+    if (greedy) {
+        best = block_max_u64(best, scr);
+        if (tid == 0) {
+            const int token = (int)(0xFFFFFFFFu - (uint32_t)best);
+            if (a.dbg_keep) a.dbg_keep[(size_t)slot * V + (token < 0 ? 0 : (token >= V ? V - 1 : token))] = 1;      // (zeroed by the caller)
+            finish(token);
+        }
+        return;
+    }
+    // ---- max of the scaled logits: finite-or-minus-infinity floats through the order-preserving integer key
+    {
+        uint32_t b = __float_as_uint(mx + 0.0f);
+        b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+        const unsigned long long wm_ = wave_max_u64(b);
+        if (lane == 0) s_mx[wave] = wm_;
+        __syncthreads();                                   // also: every x of phase A is in LDS
+        b = (uint32_t)waves_max_u64(s_mx, lane);
+        b = (b & 0x80000000u) ? (b & 0x7fffffffu) : ~b;
+        mx = __uint_as_float(b);
+    }
+    // ---- weights.  From here on a thread owns SPT consecutive vocabulary entries and keeps them in registers (it reads their x from LDS:
+    // the weights themselves never go through LDS).  floor(e x 2^32): e < 1 for all but the largest logits, and then the product is below
+    // 2^32 and one v_cvt_u32_f32 (truncation) is the floor; the general 64-bit conversion only where e >= 1.
+    const int v0 = tid * SPT;
+    unsigned long long wr[SPT];
+    unsigned long long wmax = 0, W = 0;
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) {
+        const float e = t3_expf(xs[v0 + i] - mx);
+        unsigned long long w = 0;
+        if (v0 + i < V) {
+            if (e >= 1.0f) w = (unsigned long long)(e * 4294967296.0f);
+            else w = (unsigned long long)t3_cvt_u32_trunc(e * 4294967296.0f);
+        }
+        wr[i] = w;
+        wmax = max_u64(wmax, w);
+        W += w;
+    }
+    T3_CLK(3);
+    {
+        const unsigned long long m_ = wave_max_u64(wmax), s_ = wave_sum_u64(W);
+        if (lane == 0) { s_wm[wave] = m_; s_ws[wave] = s_; }
+        __syncthreads();
+        wmax = waves_max_u64(s_wm, lane); W = waves_sum_u64(s_ws, lane);
+    }
+    bool resum = false;
+    if (sp.min_p > 0.0f) {
+        const double thr = (double)sp.min_p * (double)wmax;
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) if ((double)wr[i] < thr) wr[i] = 0;
+        resum = true;
+    }
+    if (sp.top_k > 0 && sp.top_k < V) {
+        unsigned long long lo = 0, hi = wmax;
+        while (lo < hi) {
+            const unsigned long long mid = lo + (hi - lo + 1) / 2;
+            unsigned long long cnt = 0;
+#pragma unroll
+            for (int i = 0; i < SPT; ++i) cnt += (wr[i] >= mid) ? 1 : 0;
+            cnt = block_sum_u64(cnt, scr);
+            if (cnt >= (unsigned long long)sp.top_k) lo = mid; else hi = mid - 1;
+        }
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) if (wr[i] < lo) wr[i] = 0;
+        resum = true;
+    }
+    T3_CLK(4);
+    if (sp.top_p < 1.0f) {
+        if (resum) {
+            W = 0;
+#pragma unroll
+            for (int i = 0; i < SPT; ++i) W += wr[i];
+            W = block_sum_u64(W, scr);
+        }
+        const unsigned long long Tm = (unsigned long long)((1.0 - (double)sp.top_p) * (double)W);
+        // lo = max{mid : sum of weights < mid is <= Tm} is the weight value at which the ascending cumulative
+        // mass first exceeds Tm.  Radix descent on the value: one round over the octaves, then 6 bits per
+        // round; per round an LDS histogram of masses (exact integer sums, so order-free) and a 64-bin scan.
+        T3_CLK(5);
+        // The histogram is kept in HC copies, one per lane group (lane & (HC - 1)): the masses of a round fall into a handful of the 64
+        // bins (a softmax's weights share few octaves), and 64-bit LDS atomics of one wave instruction onto the same bin serialise.  The sums
+        // are exact integers, so the copies add up to the same histogram in any order.
+        // A bin word carries the mass in its low 48 bits (all of them together stay below 8 194 x 2^32 < 2^46) and the NUMBER of entries above:
+        // when the descent ends on a single value, the chosen bin's count is the number of ties and the mass below it is `base`.
+        // The sixteen waves are bound by instruction issue, so a round spends as few instructions as it can: a thread keeps a bit mask of its
+        // entries that still match the prefix (a wave without any skips the round's loop), and ONE wave scans the 64 bins and leaves the
+        // chosen bin, the mass below it and its count in LDS for the others (wave 1 clears the other histogram meanwhile): two barriers
+        // per round.  A round is a chain of latencies (LDS atomics, barrier, four-copy reads, 64-bit scan, barrier: ~0.85 us,
+        // tools/sampler_clk.py), and a 33-bit weight is seven rounds deep -- but the entries of the chosen bin are usually ONE value long
+        // before that (a handful of entries per bin after two rounds; and logits that went through bf16 tie in droves): the rounds behind
+        // the octave round also keep every bin's smallest and largest entry, and the descent ends as soon as the chosen bin's two agree.
+        constexpr unsigned long long M48 = (1ull << 48) - 1, ONE = 1ull << 48;
+        unsigned long long* s_res = s_dr + SWV;          // [4]: chosen bin + 1 (0: none), mass below it inside the round, its word
+        unsigned long long lo = wmax, base = 0, prefix = 0, below = 0, ties = 0;
+        bool counted = false;                            // below / ties known from the descent
+        int nb = -1;                                     // bits of the value still undetermined; -1: octave round
+        uint32_t cand = 0;
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) cand |= wr[i] ? (1u << i) : 0u;
+        for (int rd = 0;; ++rd) {
+            unsigned long long* hist = psum + (rd & 1) * HSZ;
+            unsigned long long* myhist = hist + (lane & (HC - 1)) * 64;
+            unsigned long long* mymin = hmin + (rd & 1) * HSZ + (lane & (HC - 1)) * 64;
+            unsigned long long* mymax = hmax + (rd & 1) * HSZ + (lane & (HC - 1)) * 64;
+            if (cand) {
+                if (nb < 0) {
+#pragma unroll
+                    for (int i = 0; i < SPT; ++i) if (wr[i]) atomicAdd(&myhist[64 - __clzll((long long)wr[i])], wr[i] + ONE);
+                } else {
+                    const int shift = nb > 6 ? nb - 6 : 0;
+                    const unsigned long long msk = (1ull << (nb - shift)) - 1;
+#pragma unroll
+                    for (int i = 0; i < SPT; ++i) {
+                        if (!((cand >> i) & 1u)) continue;
+                        if ((wr[i] >> nb) == prefix) {
+                            const int bin = (int)((wr[i] >> shift) & msk);
+                            atomicAdd(&myhist[bin], wr[i] + ONE);
+                            atomicMin(&mymin[bin], wr[i]); atomicMax(&mymax[bin], wr[i]);
+                        } else cand &= ~(1u << i);
+                    }
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const unsigned long long own = (hist[lane] + hist[64 + lane]) + (hist[128 + lane] + hist[192 + lane]);
+                const unsigned long long c = wave_scan_u64(own, lane);      // inclusive scan over the 64 bins (masses and counts side by side)
+                const unsigned long long over = __ballot(base + (c & M48) > Tm);
+                const int b = over ? __ffsll((long long)over) - 1 : 0;
+                const unsigned long long add = readlane_u64(c - own, b) & M48, word = readlane_u64(own, b);
+                const unsigned long long* mn = hmin + (rd & 1) * HSZ; const unsigned long long* mxh = hmax + (rd & 1) * HSZ;
+                unsigned long long lowest = mn[lane], highest = mxh[lane];
+#pragma unroll
+                for (int k = 1; k < HC; ++k) { const unsigned long long a_ = mn[64 * k + lane], b_ = mxh[64 * k + lane]; lowest = a_ < lowest ? a_ : lowest; highest = max_u64(highest, b_); }
+                const unsigned long long one = (lowest == highest) ? lowest : 0ull;      // octave round: no entries here (~0 against 0)
+                const unsigned long long same = readlane_u64(one, b);
+                if (lane == 0) { s_res[0] = over ? (unsigned long long)(b + 1) : 0ull; s_res[1] = add; s_res[2] = word; s_res[3] = same; }
+            } else if (wave == 1 % SWV) {
+                for (int j = lane; j < HSZ; j += 64) {       // the other set: last read in round rd - 1 (before that round's second barrier)
+                    const int o = ((rd + 1) & 1) * HSZ + j;
+                    psum[o] = 0; hmin[o] = ~0ull; hmax[o] = 0;
+                }
+            }
+            __syncthreads();
+            const int b1 = (int)s_res[0];
+            if (!b1) break;                              // only in the octave round, when Tm == W: lo = wmax
+            const int b = b1 - 1;
+            base += s_res[1];
+            if (s_res[3]) { lo = s_res[3]; below = base; ties = s_res[2] >> 48; counted = true; break; }      // the chosen bin holds one value
+            if (nb < 0) { prefix = 1; nb = b - 1; }
+            else { const int shift = nb > 6 ? nb - 6 : 0; prefix = (prefix << (nb - shift)) | (unsigned long long)b; nb = shift; }
+            if (nb == 0) { lo = prefix; below = base; ties = s_res[2] >> 48; counted = true; break; }
+        }
+        T3_CLK(6);
+        if (lo > 0) {
+            if (!counted) {                              // degenerate threshold (Tm == W): lo = wmax, counted the long way
+                unsigned long long my_ties = 0;
+#pragma unroll
+                for (int i = 0; i < SPT; ++i) { below += (wr[i] < lo) ? wr[i] : 0; my_ties += (wr[i] == lo) ? 1 : 0; }
+                below = block_sum_u64(below, scr);
+                ties = block_sum_u64(my_ties, scr);
+            }
+            unsigned long long r = (Tm - below) / lo;
+            if (lo == wmax && r > ties - 1) r = ties - 1;
+            if (r > ties) r = ties;
+            // the r ties of highest index are dropped.  r == 0 / r == ties need no ranks.
+            unsigned long long above = 0;                // ties owned by higher threads
+            if (r > 0 && r < ties) {
+                unsigned long long my_ties = 0;
+#pragma unroll
+                for (int i = 0; i < SPT; ++i) my_ties += (wr[i] == lo) ? 1 : 0;
+                const unsigned long long incl_w = wave_scan_u64(my_ties, lane);
+                if (lane == 63) s_ti[wave] = incl_w;
+                __syncthreads();
+                unsigned long long tot;
+                above = ties - (incl_w + waves_before_u64(s_ti, lane, wave, &tot));
+            } else if (r == 0) above = ties;             // nobody's rank from the top is below 0
+#pragma unroll
+            for (int i = SPT - 1; i >= 0; --i) {
+                if (wr[i] < lo) wr[i] = 0;
+                else if (wr[i] == lo) { if (above < r) wr[i] = 0; ++above; }
+            }
+        }
+    }
+    T3_CLK(7);
+    if (a.dbg_keep) {                                   // parity hook: the support of the draw (what the masks left)
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) if (v0 + i < V) a.dbg_keep[(size_t)slot * V + v0 + i] = wr[i] != 0;
+    }
+    // ---- draw
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) mine += wr[i];
+    unsigned long long Wk = 0, excl;
+    {
+        const unsigned long long incl_w = wave_scan_u64(mine, lane);
+        if (lane == 63) s_dr[wave] = incl_w;
+        __syncthreads();
+        excl = incl_w + waves_before_u64(s_dr, lane, wave, &Wk) - mine;
+    }
+    T3_CLK(8);
+    uint32_t rnd[4];
+    philox4x32_10(step, (uint32_t)sp.uid, (uint32_t)(sp.uid >> 32), 0u, (uint32_t)sp.seed, (uint32_t)(sp.seed >> 32), rnd);
+    const unsigned long long uu = ((unsigned long long)rnd[1] << 32) | rnd[0];
+    const unsigned long long target = __umul64hi(uu, Wk);
+    T3_CLK(9);
+    // Exactly one thread owns the target (the threads' [excl, excl + mine) tile [0, Wk)) and writes the id out itself.  No thread owns it
+    // when there is no mass at all (NaN logits: a checkpoint or conditioning with NaN / Inf makes every weight 0): the draw then falls back
+    // to the stop id.
+    if (Wk == 0) {
+        if (tid == 0) finish((sp.stop_token >= 0 && sp.stop_token < V) ? sp.stop_token : 0);
+    } else if (mine > 0 && target >= excl && target < excl + mine) {
+        unsigned long long cum = excl; int found = -1;      // first entry whose running mass passes the target
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) { cum += wr[i]; if (found < 0 && cum > target) found = v0 + i; }
+        finish(found);
     }
 }
 hipError_t prepare_kernels() {
     gemm_refresh_switches();
     static bool done[MAX_DEVICES] = {};
     if (done[cur_device()]) return hipSuccess;
-    const size_t lds = (size_t)(SLOTS + SSCR + 256) * sizeof(unsigned long long);
+    const size_t lds = (size_t)(SLOTS / 2 + SSCR + 6 * 256) * sizeof(unsigned long long);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) e = prepare_gemm2();
     if (e == hipSuccess) done[cur_device()] = true;
@@ -406,7 +529,7 @@ hipError_t prepare_kernels() {
 }
 hipError_t launch_sampler(const SampleArgs& a, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
-    const size_t lds = (size_t)(SLOTS + SSCR + 256) * sizeof(unsigned long long);
+    const size_t lds = (size_t)(SLOTS / 2 + SSCR + 6 * 256) * sizeof(unsigned long long);
     hipError_t e = prepare_kernels();
     if (e != hipSuccess) return e;
     launch_k(sampler_kernel, dim3(a.n), dim3(STH), lds, s, a);
