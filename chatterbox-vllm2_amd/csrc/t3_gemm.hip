@@ -114,6 +114,7 @@ template <int MT, int NT, int KBS> constexpr int gemm2_afd() { return MT == 1 ? 
 template <int MT, int NT, int EPI, int NW, int KBS, bool NORM, int AV = KBS, int EWV = gemm2_ew<NW>()>
 __global__ __launch_bounds__((NW + EWV) * 64, (NW == 4 && EWV == 0 && MT * NT >= 8) ? 2 : 1) void gemm2_kernel(GemmArgs a) {
     T3_G2STAMP(0);
+    if (a.gx_real && (int)blockIdx.x >= a.gx_real) return;       // padding of the grid (launch_gemm2_av)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];      // [NW waves][MT][16 rows][KBS * 64 B] | NORM: float [NW][MT*16]
     static_assert(NT <= KBS && (KBS == 8 || KBS == 2) && (NW == 4 || NW == 16) && AV >= 1 && AV <= KBS && (AV == KBS || MT == 1), "gemm2 shapes");
     constexpr int LPR = KBS * 4, RPI = 64 / LPR;                // lanes (= 16-byte chunks) per row slice, rows per wave instruction
@@ -771,6 +772,111 @@ __global__ __launch_bounds__(NW * 64) void gemm2_loop_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// down_proj from ~113 rows on (decode steps of 57+ utterances, C4): TWO n-tiles per workgroup.  With one n-tile per workgroup
+// (gemm2_loop_kernel<1, 1, EPI_RESID, 16, 8>) the launch is what a CU can take in from L2 (~70 GB/s): at 256 rows 128 KiB of weights +
+// 4 x 128 KiB of rows per workgroup = 164 MB through L2 per launch, 11.8 us.  Two tiles per workgroup (32 x 8 workgroups at 256 rows:
+// 256 KiB of weights + 2 x 128 KiB of rows each) is the balanced cut of the same work, 20 % less per CU -- but two tiles of a 256-deep K
+// slice are 64 registers, and with the rows staged through registers as well (32) the sixteen-wave workgroup's 128 are gone
+// (profiles/NOTES.md).  Here the rows come by LDS-DMA straight into the wave's own (swizzled) image: a wave reads a group's eight A
+// fragments into registers, asks for the NEXT group's rows into the same image, and runs its sixteen MFMAs from registers while they
+// fly; the partials have LDS of their own (128 KiB of images + 32 KiB of partials = all of a CU's LDS).
+// Same numbers: per output the sixteen segment chains and the fold of gemm2_kernel's 16-wave form.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gemm2_down2_kernel(GemmArgs a) {
+    constexpr int KBS = 8, NT = 2, NW = 16, AIMG = 16 * KBS * 64, PFL = NT * 256;       // a wave's A image: 16 rows x 512 B; its partials: [2 tiles][4][64] floats
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];                  // [16] A images | [16] partials
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int KB = a.K >> 5, kb0 = wave * KBS;
+    const unsigned char* aimg = lds2 + (size_t)wave * AIMG;
+    const unsigned img = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds2 + (unsigned)(wave * AIMG);
+    float* pbase = reinterpret_cast<float*>(lds2 + (size_t)NW * AIMG);
+    float* myp = pbase + (size_t)wave * PFL;
+    const int mgroups = (a.M + 15) / 16;
+    const int g0 = blockIdx.y, gs = gridDim.y;
+    const int ng = g0 < mgroups ? (mgroups - g0 + gs - 1) / gs : 0;
+    if (ng == 0) return;
+    const int drow = lane >> 5, dpos = lane & 31;
+    auto issue_a = [&](int g) {                                  // 8 pieces of 1 KiB: rows 2 t, 2 t + 1 of the group, this wave's K slice
+        int dr_ = drow, dp_ = dpos;
+        asm volatile("" : "+v"(dr_), "+v"(dp_));                 // (opaque per call: hipcc would keep the eight pieces' offsets in registers across the group loop, and this kernel has none to spare)
+        const int drow = dr_, dpos = dp_;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = 2 * t + drow;
+            int m = g * 16 + row; m = m < a.M ? m : a.M - 1;
+            glds16(a.X + (size_t)m * a.K + kb0 * 32 + ((dpos ^ (row & 15)) << 3), img + t * 1024);
+        }
+    };
+    // the residual operand of this thread's output (threads 0..511: tile tid >> 8): a compiler-counted load
+    const int tl = tid >> 8, fr = (tid >> 6) & 3, fl = tid & 63;
+    const int n_out = (blockIdx.x * NT + tl) * 16 + (fl & 15);
+    auto load_res = [&](int g) -> uint16_t {
+        const int m = g * 16 + 4 * (fl >> 4) + fr;
+        if (tid < 256 * NT && m < a.M && n_out < a.N) return reinterpret_cast<const uint16_t*>(a.out)[(size_t)m * a.ldo + n_out];
+        return 0;
+    };
+    auto fold = [&](int g, uint16_t hres) {
+        if (tid < 256 * NT) {
+            const int m = g * 16 + 4 * (fl >> 4) + fr;
+            if (m < a.M && n_out < a.N) {
+                const int o = (tl * 4 + fr) * 64 + fl;
+                float tot = 0.0f;
+#pragma unroll
+                for (int gsum = 0; gsum < 4; ++gsum) {
+                    float s4 = pbase[(size_t)(4 * gsum) * PFL + o];
+                    s4 = s4 + pbase[(size_t)(4 * gsum + 1) * PFL + o]; s4 = s4 + pbase[(size_t)(4 * gsum + 2) * PFL + o]; s4 = s4 + pbase[(size_t)(4 * gsum + 3) * PFL + o];
+                    tot = gsum == 0 ? s4 : tot + s4;
+                }
+                reinterpret_cast<uint16_t*>(a.out)[(size_t)m * a.ldo + n_out] = (uint16_t)f2bf(bf2f(hres) + rbf(tot));     // h = bf16(h + bf16(y))
+            }
+        }
+    };
+    uint16_t hres = load_res(g0);                                // the oldest load: the hand-counted waits below only count what is younger than their target
+    issue_a(g0);
+    uint4_v wr[KBS][NT];
+#pragma unroll
+    for (int kb = 0; kb < KBS; ++kb)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gload16_nt(wr[kb][t], a.Wp + ((size_t)(blockIdx.x * NT + t) * KB + kb0 + kb) * 64 + lane);
+    wait_vmcnt<KBS * NT>();                                      // the first group's rows are in the image (the sixteen weight tiles are younger)
+    for (int j = 0; j < ng; ++j) {
+        const int g = g0 + j * gs;
+        const bool next = j + 1 < ng;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        constexpr int AFD = 3;                                   // A fragments this many k-blocks ahead of their MFMAs
+        uint4 afr[AFD];
+#pragma unroll
+        for (int d = 0; d < AFD; ++d) afr[d] = *reinterpret_cast<const uint4*>(aimg + a_img_off<KBS>(c, 4 * d + q));
+        static_for([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            const uint4 af = afr[kb % AFD];
+            if constexpr (kb + AFD < KBS) afr[kb % AFD] = *reinterpret_cast<const uint4*>(aimg + a_img_off<KBS>(c, 4 * (kb + AFD) + q));
+            if (j == 0) wait_vmcnt<(KBS - 1 - kb) * NT>();       // first group: this k-block's two weight tiles have landed (the later tiles are younger)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) landed(wr[kb][t]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag4(wr[kb][t]), acc[t], 0, 0, 0);
+        }, std::make_integer_sequence<int, KBS>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every fragment of the image is in registers: it may be overwritten
+        if (next) issue_a(g + gs);                               // flies under the partial writes, the fold and its two barriers
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) myp[(t * 4 + r) * 64 + lane] = acc[t][r];
+        if (j > 0) hres = load_res(g);                           // (behind the next group's pieces: the compiler's own wait for it covers them too)
+        __syncthreads();
+        fold(g, hres);
+        if (next) {
+            __syncthreads();                                     // every thread is done with this group's partials
+            wait_vmcnt<0>();                                     // the next group's rows are in the image
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Prefill-sized GEMM (M >= 256 rows): the same numbers as gemm2_kernel, another schedule.  A workgroup of four waves owns a
 // 128-row x 64-column tile (4 packed n-tiles); every K step of 32 is staged once through LDS (activations 128 x 64 B row
 // pieces; weights: 4 packed 1 KiB fragments, the NORM forms' carrying the norm weight) and feeds 32 MFMAs, so a weight byte is
@@ -1129,6 +1235,8 @@ static hipError_t launch_pgemm2_t(const GemmArgs* a, const float* rs, dim3 grid,
 
 static int g_pgemm_min_rows = -1, g_pgemm_wide_rows = -1;
 static int g_pgemm2_min_wgs = 192, g_pgemm2_all = 0;
+static int g_gemm_down2_min = 113;      // T3_GEMM_DOWN2_MIN_ROWS
+static int g_gemm_pad_gx = 1;      // T3_GEMM_PAD_GX=0: no padding of a decode GEMM's grid to whole XCD rounds (launch_gemm2_av)
 static int g_gemm_pipe = 1, g_gemm_head_2percu = 1, g_gemm_pipe_qkv_min = 129, g_gemm_pipe_min = 49;      // T3_GEMM_PIPE / T3_GEMM_HEAD_2PERCU / T3_GEMM_PIPE_QKV_MIN_ROWS (measurement switches, re-read with the next one)
 static int g_gemm_small_m = 1;          // T3_GEMM_SMALL_M=0: the one-tile GEMMs issue every activation-row load (read again by every prepare_kernels call, i.e. per engine)
 void set_pgemm_min_rows(int rows) { g_pgemm_min_rows = rows; }
@@ -1221,7 +1329,14 @@ static hipError_t launch_gemm2_av(const GemmArgs* a, hipStream_t s) {
     const int ntiles = a->packed_tiles > 0 ? a->packed_tiles / (EPI == EPI_SILU ? 2 : 1) : (a->N + 15) / 16;
     const int gx = (EPI == EPI_SILU) ? (ntiles + NT / 2 - 1) / (NT / 2) : (ntiles + NT - 1) / NT;
     const int gy = ((a->M + 15) / 16 + MT - 1) / MT;
-    launch_k(kern, dim3(gx, gy), dim3((NW + EWV) * 64), lds, s, *a);
+    // Workgroup L = y * gx + x runs on XCD L % 8, and the gy workgroups of one tile group x read the SAME weight tiles: with gx a multiple of
+    // 8 they share one XCD's L2 (gate/up at 64 rows: 128 x 2), with any other gx every one of them fetches the tiles into another L2 -- the
+    // speech head (129 tile groups) pulled its 16.8 MB twice at 64 rows and eight times at 256 (11.6 us against gate/up's 7.1 for the same
+    // bytes).  The grid is padded to the next multiple of 8; the extra workgroups leave at once.
+    GemmArgs b = *a;
+    int gxl = gx;
+    if (g_gemm_pad_gx && gy > 1 && (gx & 7) && gx > 8) { gxl = (gx + 7) & ~7; b.gx_real = gx; }
+    launch_k(kern, dim3(gxl, gy), dim3((NW + EWV) * 64), lds, s, b);
     return hipGetLastError();
 }
 // picks AV (see gemm2_kernel): the fewest A-row instructions that cover the rows of a one-tile call
@@ -1306,6 +1421,23 @@ static hipError_t launch_gemm2_loop_t(const GemmArgs* a, hipStream_t s) {
     launch_k(kern, dim3(gx, gy), dim3(NW * 64), lds, s, *a);
     return hipGetLastError();
 }
+static hipError_t launch_gemm2_down2(const GemmArgs* a, hipStream_t s) {
+    constexpr size_t lds = (size_t)16 * 8192 + (size_t)16 * 2 * 1024;       // 160 KiB: all of a CU's LDS
+    static bool raised[MAX_DEVICES] = {};
+    if (!raised[cur_device()]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_down2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised[cur_device()] = true;
+    }
+    if (!a) return hipSuccess;
+    static int split_env = -1;
+    if (split_env < 0) { const char* e = getenv("T3_GEMM_DOWN2_SPLIT"); split_env = e ? atoi(e) : 0; }
+    const int mgroups = (a->M + 15) / 16, gx = a->N / 32;
+    int gy = split_env > 0 ? split_env : std::max(1, 256 / gx);
+    while (gy > 1 && mgroups / gy < 1) --gy;
+    launch_k(gemm2_down2_kernel, dim3(gx, gy), dim3(1024), lds, s, *a);
+    return hipGetLastError();
+}
 // NORM forms (4 waves, K = 1024): MT in {1, 2}, NT in {1, 2, 3, 4}
 static hipError_t launch_gemm2_norm(const GemmArgs* a, int epi, int mt, int nt, hipStream_t s) {
 #define T3_G2(E, MTV, NTV) return launch_gemm2_t<MTV, NTV, E, 4, 8, true>(a, s)
@@ -1330,6 +1462,7 @@ void gemm_refresh_switches() {
     auto rd = [](const char* name, int dflt) { const char* ev = getenv(name); return ev ? atoi(ev) : dflt; };
     g_gemm_small_m = rd("T3_GEMM_SMALL_M", 1); g_gemm_pipe = rd("T3_GEMM_PIPE", 1);
     g_pgemm2_min_wgs = rd("T3_PGEMM2_MIN_WGS", 192); g_pgemm2_all = rd("T3_PGEMM2_ALL", 0);
+    g_gemm_pad_gx = rd("T3_GEMM_PAD_GX", 1); g_gemm_down2_min = rd("T3_GEMM_DOWN2_MIN_ROWS", 113);
     g_gemm_head_2percu = rd("T3_GEMM_HEAD_2PERCU", 1); g_gemm_pipe_qkv_min = rd("T3_GEMM_PIPE_QKV_MIN_ROWS", 129); g_gemm_pipe_min = rd("T3_GEMM_PIPE_MIN_ROWS", 49);
 }
 hipError_t prepare_gemm2() {
@@ -1357,6 +1490,7 @@ hipError_t prepare_gemm2() {
     if ((e = launch_pgemm2_t<EPI_F32, 4, false>(nullptr, nullptr, dim3(), nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_pipe<3, EPI_BF16>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 8, false>(nullptr, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm2_down2(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<1, 2, EPI_RESID, 16, 2, false>(nullptr, nullptr)) != hipSuccess) return e;
     if ((e = launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 2, false>(nullptr, nullptr)) != hipSuccess) return e;
     return hipSuccess;
@@ -1380,9 +1514,11 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
         // epilogue waves the weights-stationary forms hold their per-row cost far beyond the old switches -- gate/up 21.9 | 27.9 | 41.0 us at
         // 545 | 800 | 1 280 rows against 32.8 | 34.6 | 58.8 on the LDS-tiled schedule (which also pays a row-statistic launch), level at 2 048
         // (61.8 both); qkv level at ~1 100 (20.4 | 20.9 at 1 024, 24.3 | 23.5 at 1 280); o looped 13.2 | 19.9 at 1 280, level at 2 048; down
-        // level from 1 280 to 1 600.  The mixed steps of continuous batching (256 decode rows + a prompt: 300-1 100 rows) now stay on them.
+        // level from 1 280 to 1 600 -- and with two n-tiles per workgroup (gemm2_down2_kernel) 31.4 | 47.6 at 1 600 rows, 37.0 | 49.2 at 2 048,
+        // 51.4 | 52.6 at 3 072, 58.7 | 56.2 at 3 584 (profiles/r04_aq_down2_vs_tiled.txt): down switches at 3 072.
+        // The mixed steps of continuous batching (256 decode rows + a prompt: 300-1 100 rows) now stay on them.
         const int pg_min = g_pgemm_min_rows != -2 ? g_pgemm_min_rows
-                         : epi == EPI_SILU ? 2048 : (nw == 4 ? (a.row_index ? 1024 : 1152) : (a.K == D ? 2048 : 1600));
+                         : epi == EPI_SILU ? 2048 : (nw == 4 ? (a.row_index ? 1024 : 1152) : (a.K == D ? 2048 : 3072));
         if (pg_min > 0 && a.M >= pg_min) {
             const hipError_t pe = launch_pgemm(a, epi, s);
             if (pe != hipErrorNotSupported) return pe;
@@ -1459,6 +1595,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             if (loop16_min_o > 0 && a.M >= loop16_min_o && nt16 == 2 && a.N % 32 == 0 && a.K == D)
                 return launch_gemm2_loop_t<1, 2, EPI_RESID, 16, 2, false>(&a, s);
         }
+        // down_proj with two n-tiles per workgroup and the rows by LDS-DMA (gemm2_down2_kernel) from T3_GEMM_DOWN2_MIN_ROWS rows on (0 = never)
+        if (g_gemm_down2_min > 0 && a.M >= g_gemm_down2_min && a.K == F && a.N % 32 == 0) return launch_gemm2_down2(&a, s);
         if (loop16_min > 0 && a.M >= loop16_min)
             return a.K == D ? launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 2, false>(&a, s) : launch_gemm2_loop_t<1, 1, EPI_RESID, 16, 8, false>(&a, s);
     }

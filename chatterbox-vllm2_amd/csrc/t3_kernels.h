@@ -52,6 +52,7 @@ struct GemmArgs {
     int packed_tiles = 0;    // > 0: the packed weight holds this many n-tiles (zero rows beyond N), so tile groups may overhang N
     float* rstd_scratch = nullptr;   // [M] floats: lets the NORM forms take the prefill-sized schedule (row statistic in its own pass)
     PrefetchArgs pf;                 // gemm2_kernel, 4-wave forms: requested by the epilogue waves once the workgroup's own operands have landed
+    int gx_real = 0;                 // set by the launcher: > 0 = the grid's x extent was padded (to a multiple of 8), workgroups with blockIdx.x >= gx_real leave at once
 };
 
 // Host-side packing of a [N][K] bf16 matrix into MFMA-B-operand order:

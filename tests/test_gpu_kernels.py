@@ -57,6 +57,16 @@ def test_gemm_residual_epilogue_bit_exact(E, oracle, M, K):
     assert_bit_equal(E.k_gemm_resid(x, W, h), want, "h + bf16(x W^T)")
 
 
+@pytest.mark.parametrize("M,N", [(113, 1024), (545, 1024), (1100, 64), (3000, 64), (3071, 32)])
+def test_down_proj_two_tiles_per_workgroup_bit_exact(E, oracle, M, N):
+    """down_proj from 113 rows up to the prefill schedule's switch (3 072): gemm2_down2_kernel -- two n-tiles per sixteen-wave workgroup, the
+    rows by LDS-DMA into each wave's own image, the next group's rows in flight under the fold.  Ragged row counts (a partial last group), one
+    to many groups per workgroup (the narrow outputs give the launcher 128 / 256 row splits)."""
+    x = rand_bf16(M, 4096, seed=M + 7); W = rand_bf16(N, 4096, seed=N + 4, scale=0.05); h = rand_bf16(M, N, seed=5, scale=2.0)
+    y = oracle.gemm(x, W, 256).to(torch.bfloat16)
+    assert_bit_equal(E.k_gemm_resid(x, W, h), (h.float() + y.float()).to(torch.bfloat16), f"down form M={M} N={N}")
+
+
 @pytest.mark.parametrize("M,N", [(2, 3072), (64, 3072), (37, 8194), (200, 64)])
 def test_norm_folded_gemm_bit_exact(E, oracle, M, N):
     """RMSNorm folded into the projection: rstd * GEMM(bf16(h * w_ln), W), statistic accumulated from the operand stream."""
