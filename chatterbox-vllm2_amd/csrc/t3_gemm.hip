@@ -1113,7 +1113,12 @@ __global__ __launch_bounds__(256, WC == 4 ? 2 : (NSEG == 4 ? 4 : 3)) void pgemm_
 // k-blocks x 1 KiB.  Ring of 3 stages (144 KiB), filled by LDS-DMA two stages ahead, 6 pieces per wave and stage, counted vmcnt, raw barriers.
 // ------------------------------------------------------------------------------------------------
 template <int EPI, int NSEG, bool NORM>
-__global__ __launch_bounds__(512) void pgemm2_kernel(GemmArgs a, const float* rstd) {
+__global__ __launch_bounds__(NSEG == 4 ? 768 : 512) void pgemm2_kernel(GemmArgs a, const float* rstd) {
+    // LOADERS (the 4-segment forms: gate/up, qkv; 176 registers, so twelve waves fit): four more waves do nothing but feed the ring -- twelve
+    // DMA pieces per stage each, then the wait for the next stage's pieces and the stage's barrier -- and the eight MFMA waves never issue a
+    // load.  With every wave doing both (the 16-segment forms below still do: 240 registers) a stage was issue 0.24-0.40 us + MFMAs
+    // 0.40-0.55 + barrier skew 0.25 one after the other, 1.8 us for 48 KiB = 2.7 x what the CU's load path needs (profiles/NOTES.md).
+    constexpr bool LOADERS = NSEG == 4;
     constexpr int NS = 3, AHEAD = NS - 1, PP = 6;                 // ring stages; stages in flight; DMA pieces per wave and stage
     constexpr int STAGE = 2048 + 1024;                            // uint4 per stage: A image 32 KiB | B 16 KiB
     extern __shared__ __attribute__((aligned(16))) uint4 ring2[];
@@ -1134,8 +1139,44 @@ __global__ __launch_bounds__(512) void pgemm2_kernel(GemmArgs a, const float* rs
         int m = m0 + row; m = m < a.M ? m : a.M - 1;
         xsrc[j] = a.X + (size_t)m * a.K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
     }
-    const uint4* wsrc = a.Wp + ((size_t)(nt0 + wave) * KB) * 64 + lane;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring2;
+    if constexpr (LOADERS) {
+        if (wave >= 8) {
+            // loader wave lw: A pieces 8 lw .. 8 lw + 7 (image rows 64 lw .. 64 lw + 63), B tiles 2 lw, 2 lw + 1 (both k-blocks)
+            const int lw = wave - 8;
+            const uint16_t* xs_[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = 8 * (8 * lw + j) + (lane >> 3);
+                int m = m0 + row; m = m < a.M ? m : a.M - 1;
+                xs_[j] = a.X + (size_t)m * a.K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+            }
+            const uint4* ws_ = a.Wp + ((size_t)(nt0 + 2 * lw) * KB) * 64 + lane;
+            auto feed = [&](int st) {
+                const unsigned base = lds0 + (unsigned)((st % NS) * STAGE * 16);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) glds16(xs_[j] + st * 64, base + (unsigned)((8 * lw + j) * 1024));
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        glds16(ws_ + ((size_t)u * KB + 2 * st + kk) * 64, base + (unsigned)(2048 * 16 + ((2 * lw + u) * 2 + kk) * 1024));
+            };
+#pragma unroll
+            for (int k0 = 0; k0 < AHEAD; ++k0) if (k0 < NST) feed(k0);
+            for (int st = 0; st < NST; ++st) {
+                // stage st has landed (its twelve pieces of this wave; the next stage's twelve may still fly) before the barrier lets the MFMA
+                // waves onto it; behind the barrier every MFMA wave is past its reads of stage st - 1, whose buffer stage st + 2 refills
+                if (st + 1 < NST) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#ifndef T3_PG2_NOFEED
+                if (st + AHEAD < NST) feed(st + AHEAD);
+#endif
+            }
+            return;
+        }
+    }
+    const uint4* wsrc = a.Wp + ((size_t)(nt0 + wave) * KB) * 64 + lane;
     auto issue = [&](int st) {
         const unsigned base = lds0 + (unsigned)((st % NS) * STAGE * 16);
 #pragma unroll
@@ -1148,15 +1189,18 @@ __global__ __launch_bounds__(512) void pgemm2_kernel(GemmArgs a, const float* rs
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int u = 0; u < 4; ++u) { sg[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f}; gr[i][u] = sg[i][u]; if (NSEG > 4) tot[i][u] = sg[i][u]; }
+    if constexpr (!LOADERS) {
 #pragma unroll
-    for (int k0 = 0; k0 < AHEAD; ++k0) if (k0 < NST) issue(k0);
+        for (int k0 = 0; k0 < AHEAD; ++k0) if (k0 < NST) issue(k0);
+    }
     const int c = lane & 15, q = lane >> 4;
     int kin = 0, seg = 0;
     for (int st = 0; st < NST; ++st) {
         // stage st has landed once every wave has seen its own six pieces of it (vmcnt retires in issue order; the pieces of the next
         // stage may still fly).  lgkmcnt(0): this wave's fragment reads of the previous stage are back, so the buffer refilled below is
         // free once every wave is past the barrier.  A raw barrier: __syncthreads() would drain the DMA queue.
-        if (st + 1 < NST) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PP) : "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (LOADERS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else { if (st + 1 < NST) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PP) : "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
         __builtin_amdgcn_s_barrier();
         const uint4* As = ring2 + (st % NS) * STAGE;
         const uint4* Bs = As + 2048;
@@ -1165,30 +1209,45 @@ __global__ __launch_bounds__(512) void pgemm2_kernel(GemmArgs a, const float* rs
         // idles while the matrix pipes run and the other way round.  Waves w and w + 4 share a SIMD: the first four issue, then compute;
         // the other four compute, then issue (into the buffer of stage st - 1: every wave is past its reads of it, barrier above).
         const bool issue_first = wave < 4;
-        if (issue_first && st + AHEAD < NST) issue(st + AHEAD);
+        if (!LOADERS && issue_first && st + AHEAD < NST) issue(st + AHEAD);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            uint4 af[4], bf[4];
+            // The weight fragments of the k-block and ONE activation fragment ahead of the MFMAs that use it: with all eight fragments asked for
+            // at once the 4-segment forms (168 registers: twelve waves) had none left, and hipcc read the second k-block's activation fragments
+            // one by one, each behind a full lgkmcnt(0) in front of its four MFMAs (six exposed LDS round trips per stage).
+            uint4 bf[4], acur, anxt;
+            auto read_a = [&](int i) { const int row = wm * 64 + i * 16 + c; return As[row * 8 + ((4 * kk + q) ^ ((row >> 1) & 7))]; };
+#ifdef T3_PG2_NOREAD      // ablation (tools/): no fragment reads
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const int row = wm * 64 + i * 16 + c; af[i] = As[row * 8 + ((4 * kk + q) ^ ((row >> 1) & 7))]; }
+            for (int u = 0; u < 4; ++u) bf[u] = make_uint4(u, lane, st, kk);
+            acur = make_uint4(lane, kk, 0, st);
+#else
 #pragma unroll
             for (int u = 0; u < 4; ++u) bf[u] = Bs[((wn * 4 + u) * 2 + kk) * 64 + lane];
-            if (kk == 0 && kin == 0) {            // a segment's chain starts from +0: the accumulator operand is a zero tuple, nothing is cleared
-                const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acur = read_a(0);
+#endif
+            const bool fresh = kk == 0 && kin == 0;   // a segment's chain starts from +0: the accumulator operand is a zero tuple, nothing is cleared
+            const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+#ifndef T3_PG2_NOREAD
+                if (i < 3) anxt = read_a(i + 1);
+#endif
+#ifdef T3_PG2_NOMFMA      // ablation (tools/): the fragments are read and dropped
+                asm volatile("" :: "v"(acur.x), "v"(acur.w), "v"(bf[i].x), "v"(bf[i].w));
+#else
+                if (fresh) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(bf[u]), as_frag(af[i]), zero, 0, 0, 0);      // D = W X^T: see pgemm_store4
-            } else {
+                    for (int u = 0; u < 4; ++u) sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(bf[u]), as_frag(acur), zero, 0, 0, 0);      // D = W X^T: see pgemm_store4
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(bf[u]), as_frag(af[i]), sg[i][u], 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) sg[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(bf[u]), as_frag(acur), sg[i][u], 0, 0, 0);
+                }
+#endif
+                acur = anxt;
             }
         }
-        if (!issue_first && st + AHEAD < NST) issue(st + AHEAD);
+        if (!LOADERS && !issue_first && st + AHEAD < NST) issue(st + AHEAD);
         if (++kin == spseg) {                    // segment complete: fold it
             const bool first_in_group = (seg & 3) == 0, last_in_group = (seg & 3) == 3;
 #pragma unroll
@@ -1229,7 +1288,7 @@ static hipError_t launch_pgemm2_t(const GemmArgs* a, const float* rs, dim3 grid,
         raised[cur_device()] = true;
     }
     if (!a) return hipSuccess;
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, *a, rs);
+    hipLaunchKernelGGL(kern, grid, dim3(NSEG == 4 ? 768 : 512), lds, s, *a, rs);
     return hipGetLastError();
 }
 
@@ -1255,7 +1314,11 @@ static hipError_t launch_pgemm(const GemmArgs& a, int epi, hipStream_t s) {
     // qkv 23.4 | 34.5 -> 37.6 | 93.1 -> 97.4, o 11.5 | 24.8 | 56.7 -> 58.3.  With the XCD-aware tile order, the stage's DMA issue and MFMAs in
     // antiphase between the wave halves and no accumulator clearing (profiles/r04_t_pgemm_xcd_map.txt, 8 178 rows): down 84.5 (128 x 64: 119.0),
     // o 49.5 (54.5), gate/up 230 (201), qkv 93.3 (91.6): the 16-segment forms always, gate/up below 4 096 rows (T3_PGEMM2_ALL=1: every form)
-    const bool pg2_form = g_pgemm2_all || nseg == 16 || (epi == EPI_SILU && a.M < 4096);
+    // With four loader waves feeding the ring of the 4-segment forms (8 178 rows, profiles/r04_as_pgemm2_loaders.txt): gate/up 236 -> 201 (128 x 128
+    // tiles: 196), qkv 97.4 -> 72.2 (77.9); at 2 048 rows qkv 28.4 (31.1), at 4 096 46.9 (46.1): qkv joins the 256 x 128 forms.
+    // One activation fragment ahead of its MFMAs instead of eight fragments at once (r04_au_*): gate/up 196.8 at 8 178 rows (128 x 128: 196.6),
+    // 104.6 (108.3) at 4 096: gate/up at every row count too.
+    const bool pg2_form = g_pgemm2_all || nseg == 16 || epi == EPI_SILU || (epi == EPI_BF16 && norm);
     if (pg2_form && g_pgemm2_min_wgs > 0 && ntiles % 8 == 0 && (a.K & 63) == 0 && (long)(ntiles / 8) * ((a.M + 255) / 256) >= g_pgemm2_min_wgs) {
         const dim3 grid2(ntiles / 8, (a.M + 255) / 256);
         if (norm) {
