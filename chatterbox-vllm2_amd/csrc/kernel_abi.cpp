@@ -102,7 +102,10 @@ extern "C" int t3k_head_gemm(const void* h, const void* ln_w, const void* w, int
     DevBuf dh, dw, dout, dri, drs;
     K_TRY(dh.from(h, (size_t)Mh * D * 2)); K_TRY(dw.from(packed.data(), packed.size() * 2)); K_TRY(dout.alloc((size_t)M * VPAD * 2, true));
     K_TRY(dri.from(row_index, (size_t)M * 4)); K_TRY(drs.alloc((size_t)M * 4));
-    GemmArgs a{dh.as<uint16_t>(), dw.as<uint4>(), M, D, V, dout.p, VPAD, 4, 1, dri.as<int>(), HEAD_TILES, drs.as<float>()};
+    // as the engine does: a decode-only step samples every row in row order, the gather is the identity and the head reads its rows directly
+    bool identity = M == Mh;
+    for (int i = 0; identity && i < M; ++i) identity = row_index[i] == i;
+    GemmArgs a{dh.as<uint16_t>(), dw.as<uint4>(), M, D, V, dout.p, VPAD, 4, 1, identity ? nullptr : dri.as<int>(), HEAD_TILES, drs.as<float>()};
     K_TRY(launch_gemm(a, EPI_BF16, choose_mt(M, VPAD / 16, 4, true), nullptr));
     K_TRY(hipDeviceSynchronize());
     K_TRY(hipMemcpy(out_bf16, dout.p, (size_t)M * VPAD * 2, hipMemcpyDeviceToHost));

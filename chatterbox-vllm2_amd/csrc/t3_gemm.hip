@@ -1294,6 +1294,7 @@ static hipError_t launch_pgemm2_t(const GemmArgs* a, const float* rs, dim3 grid,
 
 static int g_pgemm_min_rows = -1, g_pgemm_wide_rows = -1;
 static int g_pgemm2_min_wgs = 192, g_pgemm2_all = 0;
+static int g_gemm_pipe_head = 1;         // T3_GEMM_PIPE_HEAD=0: the speech head keeps the one-shot form at every row count
 static int g_gemm_down2_min = 113;      // T3_GEMM_DOWN2_MIN_ROWS
 static int g_gemm_pad_gx = 1;      // T3_GEMM_PAD_GX=0: no padding of a decode GEMM's grid to whole XCD rounds (launch_gemm2_av)
 static int g_gemm_pipe = 1, g_gemm_head_2percu = 1, g_gemm_pipe_qkv_min = 129, g_gemm_pipe_min = 49;      // T3_GEMM_PIPE / T3_GEMM_HEAD_2PERCU / T3_GEMM_PIPE_QKV_MIN_ROWS (measurement switches, re-read with the next one)
@@ -1456,8 +1457,8 @@ static hipError_t launch_gemm2_pipe(const GemmArgs* a, hipStream_t s) {
     static int split_env = -1;
     if (split_env < 0) { const char* e = getenv("T3_GEMM_PIPE_SPLIT"); split_env = e ? atoi(e) : 0; }
     const int mgroups = (a->M + 15) / 16;
-    const int gx = (a->N / 16) / (EPI == EPI_SILU ? NT / 2 : NT);
-    int gy = split_env > 0 ? split_env : std::max(1, 256 / gx);    // workgroups per n-group: one workgroup per CU (gate/up 128 x 2, qkv 64 x 4)
+    const int gx = (a->packed_tiles > 0 ? a->packed_tiles : a->N / 16 * (EPI == EPI_SILU ? 2 : 1)) / NT;      // (the speech head: 516 packed tiles, the last ones beyond N)
+    int gy = split_env > 0 ? split_env : std::max(1, 256 / gx);    // workgroups per n-group: one workgroup per CU (gate/up 128 x 2, qkv 64 x 4, speech head 172 x 1)
     while (gy > 1 && mgroups / gy < 2) --gy;
     launch_k(kern, dim3(gx, gy), dim3(512), lds, s, *a);
     return hipGetLastError();
@@ -1525,7 +1526,7 @@ void gemm_refresh_switches() {
     auto rd = [](const char* name, int dflt) { const char* ev = getenv(name); return ev ? atoi(ev) : dflt; };
     g_gemm_small_m = rd("T3_GEMM_SMALL_M", 1); g_gemm_pipe = rd("T3_GEMM_PIPE", 1);
     g_pgemm2_min_wgs = rd("T3_PGEMM2_MIN_WGS", 192); g_pgemm2_all = rd("T3_PGEMM2_ALL", 0);
-    g_gemm_pad_gx = rd("T3_GEMM_PAD_GX", 1); g_gemm_down2_min = rd("T3_GEMM_DOWN2_MIN_ROWS", 113);
+    g_gemm_pad_gx = rd("T3_GEMM_PAD_GX", 1); g_gemm_down2_min = rd("T3_GEMM_DOWN2_MIN_ROWS", 113); g_gemm_pipe_head = rd("T3_GEMM_PIPE_HEAD", 1);
     g_gemm_head_2percu = rd("T3_GEMM_HEAD_2PERCU", 1); g_gemm_pipe_qkv_min = rd("T3_GEMM_PIPE_QKV_MIN_ROWS", 129); g_gemm_pipe_min = rd("T3_GEMM_PIPE_MIN_ROWS", 49);
 }
 hipError_t prepare_gemm2() {
@@ -1611,7 +1612,10 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int mt, hipStream_t s) {
             if (pipe == 2 && loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU) return launch_gemm2_pipe<4, EPI_SILU>(&a, s);     // 4 + 4 waves
             if (pipe && g_gemm_pipe_min > 0 && a.M >= g_gemm_pipe_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU) return launch_gemm2_pipe16(&a, s);
             // qkv the same way from T3_GEMM_PIPE_QKV_MIN_ROWS rows on (3 n-tiles per workgroup: 64 x 4 workgroups)
-            if (pipe && g_gemm_pipe_qkv_min > 0 && a.M >= g_gemm_pipe_qkv_min && !a.row_index && a.packed_tiles == 0 && a.N % 48 == 0 && epi == EPI_BF16) return launch_gemm2_pipe<3, EPI_BF16>(&a, s);
+            // ... and the speech head of a decode-only step of 65+ utterances (no row gather; 516 packed tiles = 172 groups of 3: the one-shot form
+            // streamed the 16.8 MB of weights once per 32 rows, 28 us at 256 rows)
+            if (pipe && g_gemm_pipe_qkv_min > 0 && a.M >= g_gemm_pipe_qkv_min && !a.row_index && epi == EPI_BF16 &&
+                (a.packed_tiles == 0 ? a.N % 48 == 0 : (g_gemm_pipe_head && a.packed_tiles % 3 == 0))) return launch_gemm2_pipe<3, EPI_BF16>(&a, s);
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 32 == 0 && epi == EPI_SILU && loop_nt == 4) return launch_gemm2_loop_t<2, 4, EPI_SILU, 4, 8, true>(&a, s);
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_SILU) return launch_gemm2_loop_t<2, 2, EPI_SILU, 4, 8, true>(&a, s);
             if (loop_min > 0 && a.M >= loop_min && !a.row_index && a.N % 16 == 0 && epi == EPI_BF16 && getenv("T3_GEMM_LOOP_QKV")) return launch_gemm2_loop_t<2, 1, EPI_BF16, 4, 8, true>(&a, s);

@@ -209,6 +209,16 @@ def test_speech_head_form_bit_exact(E, oracle, M):
     assert_bit_equal(E.k_head_gemm(big, ln, W, idx), want, f"speech head form M={M}")
 
 
+@pytest.mark.parametrize("M", [64, 130, 256])
+def test_speech_head_without_gather_bit_exact(E, oracle, M):
+    """A decode-only step samples every row in row order: the head reads its rows directly (no index) -- the one-shot form up to 128 rows,
+    from 129 rows (decode steps of 65+ utterances, C4) gemm2_pipe_kernel<3, BF16> over the 516 packed tiles (172 workgroups, weights stationary,
+    the last tile group overhanging the 8 194 columns)."""
+    h = rand_bf16(M, 1024, seed=M + 3, scale=2.0); ln = (rand_bf16(1024, seed=9) + 1.0).to(torch.bfloat16)
+    W = rand_bf16(8194, 1024, seed=21, scale=0.05)
+    assert_bit_equal(E.k_head_gemm(h, ln, W, list(range(M))), oracle.norm_gemm(h, ln, W).to(torch.bfloat16), f"speech head, identity gather, M={M}")
+
+
 
 @pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8, 9, 14, 16])
 def test_decode_gemms_at_few_rows(E, oracle, M):
