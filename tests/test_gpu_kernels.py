@@ -445,6 +445,26 @@ def test_sampler_ties_and_degenerate(E, oracle):
             assert tok == want, (fill, spike, kw, tok, want)
 
 
+def test_sampler_threshold_inside_tie_groups(E, oracle):
+    """The nucleus threshold landing INSIDE a group of equal weights (few-valued logits: thousands of ties per value), at the largest weight, and
+    the degenerate thresholds (top_p so small that nothing but one id survives; top_p combined with min-p / top-k, which re-sum the mass): the
+    sampler's support and id against the oracle's, bit for bit.  Exercises the rank scan among ties (0 < dropped < ties), the no-scan shortcuts
+    (none / all of the ties dropped), the descent that ends on a single-valued bin, and the counted-the-long-way path (threshold == total mass)."""
+    g = torch.Generator().manual_seed(5)
+    for levels, scale in ((2, 1.0), (5, 0.5), (16, 0.25), (200, 0.05)):
+        vals = torch.randint(0, levels, (8194,), generator=g).float() * scale
+        l2 = torch.zeros(2, 8208); l2[0, :8194] = vals; l2[1, :8194] = vals
+        l2 = l2.to(torch.bfloat16); lg = l2[0, :8194].float()
+        cnt = torch.zeros(8194, dtype=torch.int32)
+        for kw in (dict(top_p=0.5), dict(top_p=0.9), dict(top_p=0.999), dict(top_p=0.013), dict(top_p=1e-9), dict(top_p=1e-30),
+                   dict(top_p=0.7, min_p=0.3), dict(top_p=0.6, top_k=40), dict(top_p=0.95, top_k=3000, min_p=0.01)):
+            kw = dict(temperature=1.0, **kw)
+            tok, keep = E.k_sample_support(l2, cnt.to(torch.uint16), E.make_sampling(seed=9, uid=2, **kw), 0.5, 3)
+            otok, okeep = oracle.sample_support(lg, cnt, oracle.make_sampling(seed=9, uid=2, **kw), 3)
+            assert torch.equal(keep, okeep), (levels, kw, int(keep.sum()), int(okeep.sum()))
+            assert tok == otok, (levels, kw, tok, otok)
+
+
 def test_sampler_counts_update(E):
     l = torch.zeros(2, 8208).to(torch.bfloat16); l[:, 100] = 9.0
     counts = torch.zeros(8194, dtype=torch.uint16)
