@@ -112,11 +112,12 @@ def test_groups_and_graph_replay_do_not_change_ids(E, oracle, tiny_weights, tiny
     eng.close()
 
 
-@pytest.mark.parametrize("switches", [{"T3_ZERO_COPY": "0"}, {"T3_PREFETCH": "0", "T3_GEMM_SMALL_M": "0"}, {"T3_PREFETCH_DOWN_LINES": "1024"}])
+@pytest.mark.parametrize("switches", [{"T3_ZERO_COPY": "0"}, {"T3_PREFETCH": "0", "T3_GEMM_SMALL_M": "0"}, {"T3_PREFETCH_DOWN_LINES": "1024"}, {"T3_LONGEST_FIRST": "0"}])
 def test_transport_and_prefetch_switches_do_not_change_ids(E, oracle, tiny_weights, tiny_oracle, cond, switches, monkeypatch):
     """How a step's metadata and ids travel (read / written in pinned host memory by the step's own kernels, or by copy kernels), whether
     gate/up's epilogue waves fetch down_proj's weights into L2, and whether the few-row GEMM forms skip padded activation rows are
-    transport and scheduling only: with each of them switched off (the defaults are on and run in every other test) every stream --
+    transport and scheduling only (as is the order of a step's decode rows: longest context first by default, admission order with
+    T3_LONGEST_FIRST=0): with each of them switched off (the defaults are on and run in every other test) every stream --
     1, 2 and 5 utterances at a time, graph replay with run-ahead, utterances that stop at different steps -- still equals its oracle stream."""
     for k, v in switches.items():
         monkeypatch.setenv(k, v)
